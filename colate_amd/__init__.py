@@ -1,0 +1,30 @@
+"""colate_amd -- MI355X-native EM path of `Colate --mode mut`.
+
+Python here is plumbing only (ctypes over the C ABI in include/colate_amd.h, torch for
+device memory / streams / torch.distributed): the product is colate_amd/csrc (HIP + C++).
+"""
+from ._lib import LIB_PATH, ColateError  # noqa: F401
+from .api import (  # noqa: F401
+    DEFAULT_INIT_RATE,
+    DEFAULT_MAX_ITER,
+    DEFAULT_MIN_ITER,
+    DEFAULT_RATE_FLOOR,
+    DEFAULT_REL_TOL,
+    FLAG_MAXITER,
+    FLAG_NAN,
+    FLAG_NEG,
+    Rng,
+    age_grid,
+    bootstrap_counts,
+    coal_EM,
+    device_count,
+    em_batch,
+    em_batch_device,
+    em_estep,
+    em_estep_device,
+    epochs_from_bins,
+    epochs_from_coal,
+    mut_main,
+    version,
+    write_coal,
+)

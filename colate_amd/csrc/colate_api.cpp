@@ -1,0 +1,234 @@
+// colate_amd/csrc/colate_api.cpp -- extern "C" entry points of libcolate_amd.so
+// for the EM hot path (see include/colate_amd.h).  Argument checking, device
+// buffers for the host-pointer variants, kernel launch.  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "colate_amd.h"
+#include "colate_internal.h"
+#include "em_kernels.h"
+
+static_assert(COLATE_FLAG_NAN == 1 && COLATE_FLAG_NEG == 2 && COLATE_FLAG_MAXITER == 4, "flags");
+
+namespace colate {
+
+static thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+static int hip_fail(hipError_t e, const char* what) {
+  return fail(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? COLATE_ENODEVICE : COLATE_EHIP,
+              "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                \
+  do {                                               \
+    hipError_t e_ = (expr);                          \
+    if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+  } while (0)
+
+static int check_sizes(int B, int E, int A) {
+  if (B < 0 || E < 1 || A < 1) return fail(COLATE_EINVAL, "bad sizes B=%d E=%d A=%d", B, E, A);
+  if (E > COLATE_EM_MAX_E || A > COLATE_EM_MAX_A)
+    return fail(COLATE_ELIMIT, "E=%d / A=%d above compiled limits (%d / %d)", E, A,
+                COLATE_EM_MAX_E, COLATE_EM_MAX_A);
+  return COLATE_OK;
+}
+
+static int ensure_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(COLATE_ENODEVICE, "no usable HIP device (%s); libcolate_amd has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  return COLATE_OK;
+}
+
+// grids that the kernel's contiguous-segment logic relies on
+static int check_grids(int E, int A, const double* age_grid, const double* epochs) {
+  for (int b = 0; b < A; b++) {
+    if (!(age_grid[b] >= 0.0) || (b > 0 && age_grid[b] < age_grid[b - 1]))
+      return fail(COLATE_EINVAL, "age_grid must be non-negative and non-decreasing (index %d)", b);
+  }
+  for (int e = 1; e < E; e++) {
+    if (!(epochs[e] >= epochs[e - 1]))
+      return fail(COLATE_EINVAL, "epochs must be non-decreasing (index %d)", e);
+  }
+  if (!(epochs[0] <= age_grid[0]))
+    return fail(COLATE_EINVAL, "epochs[0] must not exceed age_grid[0]");
+  return COLATE_OK;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  template <typename T>
+  T* as() {
+    return static_cast<T*>(p);
+  }
+};
+
+static int launch(const ColateEmArgs& a, hipStream_t s) {
+  if (a.B == 0) return COLATE_OK;
+  hipError_t e = colate_em_launch(a, s);
+  if (e != hipSuccess) return hip_fail(e, "EM kernel launch");
+  return COLATE_OK;
+}
+
+}  // namespace colate
+
+using namespace colate;
+
+extern "C" {
+
+const char* colate_version(void) { return "colate_amd 0.1 (gfx950)"; }
+const char* colate_last_error(void) { return g_last_error.c_str(); }
+
+int colate_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(COLATE_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+int colate_set_device(int ordinal) {
+  HIP_TRY(hipSetDevice(ordinal));
+  return COLATE_OK;
+}
+
+int colate_em_batch_device(int B, int E, int A, const double* age_grid, const double* cnt_shared,
+                           const double* cnt_notshared, const double* epochs,
+                           int epochs_per_replicate, const double* init_rates,
+                           int rates_per_replicate, int max_iter, int min_iter, double rel_tol,
+                           double rate_floor, double* out_rates, int* out_iters,
+                           double* out_loglik, int* out_flags, void* hip_stream) {
+  if (int rc = check_sizes(B, E, A)) return rc;
+  if (!age_grid || !cnt_shared || !cnt_notshared || !epochs || !init_rates || !out_rates ||
+      !out_iters || !out_loglik || !out_flags)
+    return fail(COLATE_EINVAL, "NULL pointer argument");
+  if (max_iter < 1) return fail(COLATE_EINVAL, "max_iter must be >= 1");
+  ColateEmArgs a{};
+  a.B = B, a.E = E, a.A = A, a.mode = 0;
+  a.age_grid = age_grid, a.cnt_sh = cnt_shared, a.cnt_ns = cnt_notshared;
+  a.epochs = epochs, a.epochs_stride = epochs_per_replicate ? E : 0;
+  a.rates_in = init_rates, a.rates_stride = rates_per_replicate ? E : 0;
+  a.max_iter = max_iter, a.min_iter = min_iter, a.rel_tol = rel_tol, a.rate_floor = rate_floor;
+  a.out_rates = out_rates, a.out_iters = out_iters, a.out_ll = out_loglik, a.out_flags = out_flags;
+  return launch(a, static_cast<hipStream_t>(hip_stream));
+}
+
+int colate_em_estep_device(int B, int E, int A, const double* age_grid, const double* cnt_shared,
+                           const double* cnt_notshared, const double* epochs, const double* rates,
+                           double* num_acc, double* den_acc, double* loglik, int* flags,
+                           void* hip_stream) {
+  if (int rc = check_sizes(B, E, A)) return rc;
+  if (!age_grid || !cnt_shared || !cnt_notshared || !epochs || !rates || !num_acc || !den_acc ||
+      !loglik || !flags)
+    return fail(COLATE_EINVAL, "NULL pointer argument");
+  ColateEmArgs a{};
+  a.B = B, a.E = E, a.A = A, a.mode = 1;
+  a.age_grid = age_grid, a.cnt_sh = cnt_shared, a.cnt_ns = cnt_notshared;
+  a.epochs = epochs, a.epochs_stride = 0;
+  a.rates_in = rates, a.rates_stride = E;
+  a.max_iter = 1, a.min_iter = 0, a.rel_tol = 0, a.rate_floor = 0;
+  a.out_ll = loglik, a.out_flags = flags, a.out_num = num_acc, a.out_den = den_acc;
+  return launch(a, static_cast<hipStream_t>(hip_stream));
+}
+
+int colate_em_batch(int B, int E, int A, const double* age_grid, const double* cnt_shared,
+                    const double* cnt_notshared, const double* epochs, const double* init_rates,
+                    int max_iter, int min_iter, double rel_tol, double rate_floor,
+                    double* out_rates, int* out_iters, double* out_loglik, int* out_flags) {
+  if (int rc = check_sizes(B, E, A)) return rc;
+  if (!age_grid || !cnt_shared || !cnt_notshared || !epochs || !init_rates || !out_rates ||
+      !out_iters || !out_loglik || !out_flags)
+    return fail(COLATE_EINVAL, "NULL pointer argument");
+  if (int rc = check_grids(E, A, age_grid, epochs)) return rc;
+  if (int rc = ensure_device()) return rc;
+  if (B == 0) return COLATE_OK;
+  const size_t nBA = (size_t)B * A, nBE = (size_t)B * E;
+  DevBuf d_grid, d_sh, d_ns, d_ep, d_init, d_rates, d_iters, d_ll, d_flags;
+  HIP_TRY(d_grid.alloc(A * sizeof(double)));
+  HIP_TRY(d_sh.alloc(nBA * sizeof(double)));
+  HIP_TRY(d_ns.alloc(nBA * sizeof(double)));
+  HIP_TRY(d_ep.alloc(E * sizeof(double)));
+  HIP_TRY(d_init.alloc(E * sizeof(double)));
+  HIP_TRY(d_rates.alloc(nBE * sizeof(double)));
+  HIP_TRY(d_iters.alloc(B * sizeof(int)));
+  HIP_TRY(d_ll.alloc(B * sizeof(double)));
+  HIP_TRY(d_flags.alloc(B * sizeof(int)));
+  HIP_TRY(hipMemcpy(d_grid.p, age_grid, A * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_sh.p, cnt_shared, nBA * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_ns.p, cnt_notshared, nBA * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_ep.p, epochs, E * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_init.p, init_rates, E * sizeof(double), hipMemcpyHostToDevice));
+  int rc = colate_em_batch_device(B, E, A, d_grid.as<double>(), d_sh.as<double>(),
+                                  d_ns.as<double>(), d_ep.as<double>(), 0, d_init.as<double>(), 0,
+                                  max_iter, min_iter, rel_tol, rate_floor, d_rates.as<double>(),
+                                  d_iters.as<int>(), d_ll.as<double>(), d_flags.as<int>(), nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out_rates, d_rates.p, nBE * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_iters, d_iters.p, B * sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_loglik, d_ll.p, B * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_flags, d_flags.p, B * sizeof(int), hipMemcpyDeviceToHost));
+  return COLATE_OK;
+}
+
+int colate_em_estep(int B, int E, int A, const double* age_grid, const double* cnt_shared,
+                    const double* cnt_notshared, const double* epochs, const double* rates,
+                    double* num_acc, double* den_acc, double* loglik, int* flags) {
+  if (int rc = check_sizes(B, E, A)) return rc;
+  if (!age_grid || !cnt_shared || !cnt_notshared || !epochs || !rates || !num_acc || !den_acc ||
+      !loglik || !flags)
+    return fail(COLATE_EINVAL, "NULL pointer argument");
+  if (int rc = check_grids(E, A, age_grid, epochs)) return rc;
+  if (int rc = ensure_device()) return rc;
+  if (B == 0) return COLATE_OK;
+  const size_t nBA = (size_t)B * A, nBE = (size_t)B * E;
+  DevBuf d_grid, d_sh, d_ns, d_ep, d_rates, d_num, d_den, d_ll, d_flags;
+  HIP_TRY(d_grid.alloc(A * sizeof(double)));
+  HIP_TRY(d_sh.alloc(nBA * sizeof(double)));
+  HIP_TRY(d_ns.alloc(nBA * sizeof(double)));
+  HIP_TRY(d_ep.alloc(E * sizeof(double)));
+  HIP_TRY(d_rates.alloc(nBE * sizeof(double)));
+  HIP_TRY(d_num.alloc(nBE * sizeof(double)));
+  HIP_TRY(d_den.alloc(nBE * sizeof(double)));
+  HIP_TRY(d_ll.alloc(B * sizeof(double)));
+  HIP_TRY(d_flags.alloc(B * sizeof(int)));
+  HIP_TRY(hipMemcpy(d_grid.p, age_grid, A * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_sh.p, cnt_shared, nBA * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_ns.p, cnt_notshared, nBA * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_ep.p, epochs, E * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_rates.p, rates, nBE * sizeof(double), hipMemcpyHostToDevice));
+  int rc = colate_em_estep_device(B, E, A, d_grid.as<double>(), d_sh.as<double>(),
+                                  d_ns.as<double>(), d_ep.as<double>(), d_rates.as<double>(),
+                                  d_num.as<double>(), d_den.as<double>(), d_ll.as<double>(),
+                                  d_flags.as<int>(), nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(num_acc, d_num.p, nBE * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(den_acc, d_den.p, nBE * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(loglik, d_ll.p, B * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(flags, d_flags.p, B * sizeof(int), hipMemcpyDeviceToHost));
+  return COLATE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+// colate_amd/csrc/em_kernels.h -- internal launch interface of the EM kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+#define COLATE_EM_THREADS 256
+#define COLATE_EM_MAX_E 256  // one epoch per thread
+#define COLATE_EM_MAX_A 256  // one age bin per thread
+
+// per-replicate diagnostic flags (the reference aborts on the corresponding asserts)
+#define COLATE_FLAG_NAN 1      // coal.cpp:3711-3712, coal_EM.cpp:128-129, 351
+#define COLATE_FLAG_NEG 2      // coal.cpp:3713-3714
+#define COLATE_FLAG_MAXITER 4  // iteration cap reached without meeting the stop rule
+
+struct ColateEmArgs {
+  int B, E, A;
+  int mode;                 // 0 = EM to convergence, 1 = one E-step
+  const double* age_grid;   // [A]      device
+  const double* cnt_sh;     // [B][A]   device
+  const double* cnt_ns;     // [B][A]   device
+  const double* epochs;     // [E] (epochs_stride 0) or [B][E] (epochs_stride E)
+  long epochs_stride;
+  const double* rates_in;   // initial rates (mode 0) / rates (mode 1); [E] or [B][E]
+  long rates_stride;
+  int max_iter, min_iter;
+  double rel_tol, rate_floor;
+  double* out_rates;  // [B][E] (mode 0)
+  int* out_iters;     // [B]    (mode 0)
+  double* out_ll;     // [B]
+  int* out_flags;     // [B]
+  double* out_num;    // [B][E] (mode 1)
+  double* out_den;    // [B][E] (mode 1)
+};
+
+size_t colate_em_lds_bytes(int E, int A);
+hipError_t colate_em_launch(const ColateEmArgs& args, hipStream_t stream);

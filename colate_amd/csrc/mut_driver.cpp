@@ -1,0 +1,642 @@
+// colate_amd/csrc/mut_driver.cpp -- `Colate --mode mut` as a library call
+// (colate_mut_main in include/colate_amd.h): the command line of the reference
+// (include/coal/Colate.cpp:6-116) for the .colate.in / .colate_mat inputs, the
+// feeder that turns two .colate.in streams and the .mut files into per-block
+// age-bin tables (include/coal/coal.cpp:2071-2321 with include/src/mutations.cpp:56-283
+// and include/src/data.cpp:213-235), and the mut() driver (include/coal/coal.cpp:3071-3863)
+// around the GPU EM (colate_em_batch).
+//
+// Everything here runs once per invocation on the host; the per-replicate EM,
+// which is where the reference spends its time, is the HIP kernel.
+#include <sys/resource.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "colate_amd.h"
+#include "colate_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------ options
+// Same option names as Colate.cpp:11-45 (unknown options are an error there too:
+// cxxopts throws option_not_exists_exception).  `--num_bootstrap` (README spelling)
+// is accepted as an alias of `--num_bootstraps`; `--device` is ours.
+struct Options {
+  std::map<std::string, std::string> kv;
+  bool has(const std::string& k) const { return kv.count(k) > 0; }
+  const std::string& get(const std::string& k) const { return kv.at(k); }
+};
+
+const char* const kValueOptions[] = {
+    "mode", "anc", "mut", "target_bcf", "reference_bcf", "target_mask", "reference_mask",
+    "target_table", "target_bam", "reference_bam", "target_tmp", "reference_tmp", "target_age",
+    "reference_age", "ref_genome", "anc_genome", "mask", "mask_cutoff", "chr", "bins",
+    "lineage_bin", "outgroup_tmrca", "years_per_gen", "coal", "seed", "num_bootstraps", "filters",
+    "groups", "poplabels", "map", "input", "output", "device"};
+const char* const kBoolOptions[] = {"help", "strandfilter"};
+
+bool parse_options(int argc, char** argv, Options& o, std::string& err) {
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    std::string name, value;
+    bool have_value = false;
+    if (a.rfind("--", 0) == 0) {
+      name = a.substr(2);
+      size_t eq = name.find('=');
+      if (eq != std::string::npos) {
+        value = name.substr(eq + 1);
+        name = name.substr(0, eq);
+        have_value = true;
+      }
+    } else if (a == "-i") {
+      name = "input";
+    } else if (a == "-o") {
+      name = "output";
+    } else {
+      err = "Unexpected argument '" + a + "'";
+      return false;
+    }
+    if (name == "num_bootstrap") name = "num_bootstraps";
+    bool is_bool = false, known = false;
+    for (const char* b : kBoolOptions)
+      if (name == b) is_bool = known = true;
+    for (const char* v : kValueOptions)
+      if (name == v) known = true;
+    if (!known) {
+      err = "Option '" + name + "' does not exist";
+      return false;
+    }
+    if (is_bool) {
+      o.kv[name] = "true";
+      continue;
+    }
+    if (!have_value) {
+      if (i + 1 >= argc) {
+        err = "Option '" + name + "' is missing an argument";
+        return false;
+      }
+      value = argv[++i];
+    }
+    o.kv[name] = value;
+  }
+  return true;
+}
+
+void print_help() {
+  std::cout << "Usage:\n  Colate [OPTION...]\n\n"
+            << "      --help                 Print help.\n"
+            << "      --mode arg             Choose which part of the algorithm to run (colate_amd: mut).\n"
+            << "      --mut arg              Filename of file containing mut.\n"
+            << "      --target_tmp arg       Filename of target tmp file\n"
+            << "      --reference_tmp arg    Filename of reference tmp file\n"
+            << "      --target_mask arg      Fasta file containing target mask\n"
+            << "      --reference_mask arg   Fasta file containing reference mask\n"
+            << "      --target_age arg       Target age in years\n"
+            << "      --reference_age arg    Reference age in years\n"
+            << "      --chr arg              Optional: File specifying chromosomes to use.\n"
+            << "      --bins arg             Optional: Epoch boundaries 10^(seq(x,y,stepsize)) [format: x,y,stepsize]. In years.\n"
+            << "      --years_per_gen arg    Optional: Years per generation.\n"
+            << "      --coal arg             Filename of file containing coalescence rates.\n"
+            << "      --seed arg             Optional: Seed for random number generator (int)\n"
+            << "      --num_bootstraps arg   Optional: Number of bootstraps.\n"
+            << "      --device arg           Optional (colate_amd): GPU ordinal, default 0.\n"
+            << "  -o, --output arg           Filename of output.\n"
+            << std::endl;
+}
+
+// ------------------------------------------------------------------ gz text
+// igzstream semantics of the reference: zlib reads gzip and plain files alike.
+class GzText {
+ public:
+  bool open(const std::string& name) {
+    close();
+    f_ = gzopen(name.c_str(), "rb");
+    if (f_) gzbuffer(f_, 1 << 20);
+    return f_ != nullptr;
+  }
+  bool is_open() const { return f_ != nullptr; }
+  bool getline(std::string& line) {
+    line.clear();
+    if (!f_) return false;
+    char buf[1 << 14];
+    bool got = false;
+    while (gzgets(f_, buf, sizeof(buf))) {
+      got = true;
+      size_t n = std::strlen(buf);
+      if (n && buf[n - 1] == '\n') {
+        line.append(buf, n - 1);
+        return true;
+      }
+      line.append(buf, n);
+    }
+    return got;
+  }
+  void close() {
+    if (f_) gzclose(f_);
+    f_ = nullptr;
+  }
+  ~GzText() { close(); }
+
+ private:
+  gzFile f_ = nullptr;
+};
+
+// ------------------------------------------------------------------ .mut rows
+// Only the columns parse_tmptmp looks at (mutations.cpp:77-246):
+// snp;pos;dist;rs;tree;branches;is_not_mapping;is_flipped;age_begin;age_end;anc/der;...
+struct MutRow {
+  int pos = 0;
+  int num_branches = 0;
+  int flipped = 0;
+  float age_begin = 0.0f, age_end = 0.0f;  // stored as float in the reference (mutations.hpp:21)
+  std::string mutation_type = "NA";
+};
+
+[[noreturn]] void mut_line_error(const std::string& line) {
+  std::cerr << "Error reading following line in mut file:" << std::endl;
+  std::cerr << line << std::endl;
+  std::exit(1);
+}
+
+bool read_mut_file(const std::string& filename, std::vector<MutRow>& rows) {
+  GzText is;
+  if (!is.open(filename) && !is.open(filename + ".gz")) {
+    std::cerr << "Error while reading " << filename << "(.gz)." << std::endl;
+    std::exit(1);  // mutations.cpp:265-268
+  }
+  std::string line;
+  is.getline(line);  // header
+  rows.clear();
+  std::vector<std::string> f;
+  while (is.getline(line)) {
+    // split on ';' (the reference walks the same separators field by field)
+    f.clear();
+    size_t start = 0;
+    for (;;) {
+      size_t sc = line.find(';', start);
+      if (sc == std::string::npos) {
+        f.push_back(line.substr(start));
+        break;
+      }
+      f.push_back(line.substr(start, sc - start));
+      start = sc + 1;
+    }
+    if (f.size() < 11) mut_line_error(line);  // ...;age_begin;age_end;<rest> needs 10 separators
+    MutRow r;
+    try {
+      (void)std::stoi(f[0]);
+      r.pos = std::stoi(f[1]);
+      (void)std::stoi(f[2]);
+      (void)std::stoi(f[4]);
+      std::istringstream bs(f[5]);
+      std::string tok;
+      while (bs >> tok) {
+        (void)std::stoi(tok);
+        r.num_branches++;
+      }
+      r.flipped = std::stoi(f[7]);
+      r.age_begin = std::stof(f[8]);
+      r.age_end = std::stof(f[9]);
+    } catch (...) {
+      mut_line_error(line);
+    }
+    if (!f[10].empty() || f.size() > 11) r.mutation_type = f[10];
+    rows.push_back(r);
+  }
+  return true;
+}
+
+// data.cpp:213-235: sequence = upper-cased lines after the header, concatenated
+void read_fasta_mask(const std::string& filename, std::string& seq) {
+  GzText is;
+  if (!is.open(filename) && !is.open(filename + ".gz")) {
+    std::cerr << "Error while opening file " << filename << "." << std::endl;
+    std::exit(1);
+  }
+  std::string line;
+  is.getline(line);
+  seq.clear();
+  while (is.getline(line)) {
+    for (char& c : line) c = (char)std::toupper((unsigned char)c);
+    seq += line;
+  }
+}
+
+// ------------------------------------------------------------------ .colate.in
+// Record (little-endian, no header), coal.cpp:2505-2514 / 2126-2133:
+//   int32 lchrom; char chrom[lchrom]; int32 bp; char anc; char der; int32 AAF; int32 DAF
+struct TmpStream {
+  FILE* fp = nullptr;
+  std::string chrom;  // name of the record last read ("" before any read)
+  int bp = 0;
+  char anc = 0, der = 0;
+  int AAF = 0, DAF = 0;  // the reference resets these two between SNPs (coal.cpp:2182-2183)
+  // returns false at end of file, leaving every field as it was (coal.cpp:2126 `break`)
+  bool next() {
+    int lchrom = 0;
+    if (!fp || std::fread(&lchrom, sizeof(int), 1, fp) != 1) return false;
+    char buf[1024];
+    if (lchrom < 0 || lchrom > 1023) lchrom = 0;
+    std::fread(buf, sizeof(char), (size_t)lchrom, fp);
+    chrom.assign(buf, (size_t)lchrom);
+    std::fread(&bp, sizeof(int), 1, fp);
+    std::fread(&anc, sizeof(char), 1, fp);
+    std::fread(&der, sizeof(char), 1, fp);
+    std::fread(&AAF, sizeof(int), 1, fp);
+    std::fread(&DAF, sizeof(int), 1, fp);
+    return true;
+  }
+};
+
+struct BlockTables {  // one entry per genome block; emp = row 0 of the reference's A*A tables
+  std::vector<std::vector<double>> sh, ns, sh_emp, ns_emp;
+  void add_block(int A) {
+    sh.emplace_back(A, 0.0);
+    ns.emplace_back(A, 0.0);
+    sh_emp.emplace_back(A, 0.0);
+    ns_emp.emplace_back(A, 0.0);
+  }
+};
+
+inline int age_bin_index(double x, double C) {  // coal.cpp:2265, 2284
+  const double v = std::round(std::log(10 * x) * C);
+  if (!(v > -2e9)) return 0;  // log(0) = -inf: the reference's (int) cast yields INT_MIN -> max(0, .) = 0
+  return std::max(0, (int)v + 1);
+}
+
+// coal.cpp:2071-2321.  Returns the number of blocks.
+int fill_tables_from_tmp(const std::vector<std::string>& chr_names,
+                         const std::vector<std::string>& mut_files, const std::string& target_file,
+                         const std::string& ref_file, const std::vector<std::string>& target_masks,
+                         const std::vector<std::string>& ref_masks, double C, std::mt19937& rng,
+                         int num_bases_per_block, int A, BlockTables& tab) {
+  const double age = 0, ref_age = 0;  // forced, coal.cpp:2074-2075
+  std::uniform_real_distribution<double> dist_unif(0, 1);
+  const float num_samples = 100;
+  TmpStream tgt, ref;
+  tgt.fp = std::fopen(target_file.c_str(), "rb");
+  ref.fp = std::fopen(ref_file.c_str(), "rb");
+  if (!tgt.fp) std::cerr << "Failed to open " << target_file << std::endl;
+  if (!ref.fp) std::cerr << "Failed to open " << ref_file << std::endl;
+  const bool has_tar_mask = !target_masks.empty(), has_ref_mask = !ref_masks.empty();
+
+  int num_blocks = 0;
+  size_t blk = 0;
+  tab.add_block(A);
+  auto advance_block = [&]() {
+    blk++;
+    num_blocks++;
+    if (blk >= tab.sh.size()) tab.add_block(A);
+  };
+
+  std::vector<MutRow> rows;
+  std::string tar_mask, ref_mask, ancestral, derived;
+  for (size_t chr = 0; chr < mut_files.size(); chr++) {
+    std::cerr << "parsing CHR: " << chr + 1 << " / " << mut_files.size() << std::endl;
+    read_mut_file(mut_files[chr], rows);
+    if (has_tar_mask) read_fasta_mask(target_masks[chr], tar_mask);
+    if (has_ref_mask) read_fasta_mask(ref_masks[chr], ref_mask);
+    int current_block_base = 0;
+    const std::string& name = chr_names[chr];
+    while (ref.chrom != name) {  // skip to this chromosome, coal.cpp:2125-2134
+      if (!ref.next()) break;
+    }
+    while (tgt.chrom != name) {
+      if (!tgt.next()) break;
+    }
+    for (const MutRow& m : rows) {
+      if (!(m.flipped == 0 && m.num_branches == 1 && m.age_begin < m.age_end && m.age_end >= age))
+        continue;
+      ancestral.clear();
+      derived.clear();
+      size_t i = 0;
+      while (i < m.mutation_type.size() && m.mutation_type[i] != '/') ancestral.push_back(m.mutation_type[i++]);
+      i++;
+      while (i < m.mutation_type.size()) derived.push_back(m.mutation_type[i++]);
+      const int bp_mut = m.pos;
+      if (ancestral.empty() || derived.empty()) continue;
+
+      bool use = true;
+      if (has_tar_mask && (size_t)bp_mut < tar_mask.size() && tar_mask[bp_mut - 1] != 'P') use = false;
+      if (has_ref_mask && (size_t)bp_mut < ref_mask.size() && ref_mask[bp_mut - 1] != 'P') use = false;
+      if (ancestral != "A" && ancestral != "C" && ancestral != "G" && ancestral != "T" && ancestral != "0") use = false;
+      if (derived != "A" && derived != "C" && derived != "G" && derived != "T" && derived != "1") use = false;
+
+      if (use) {  // reference sample must carry the derived allele, coal.cpp:2181-2199
+        ref.DAF = 0;
+        ref.AAF = 0;
+        while (ref.chrom == name && ref.bp < bp_mut) {
+          if (!ref.next()) break;
+        }
+        if (ref.chrom != name || ref.bp != bp_mut || ref.anc != ancestral[0] || ref.der != derived[0]) use = false;
+      }
+      if (ref.DAF == 0) use = false;
+      const int N_ref = ref.DAF + ref.AAF;
+
+      if (use) {  // coal.cpp:2201-2219
+        tgt.DAF = 0;
+        tgt.AAF = 0;
+        while (tgt.chrom == name && tgt.bp < bp_mut) {
+          if (!tgt.next()) break;
+        }
+        if (tgt.chrom != name || tgt.bp != bp_mut || tgt.anc != ancestral[0] || tgt.der != derived[0]) use = false;
+      }
+      const int N_target = tgt.DAF + tgt.AAF;
+      if (N_target == 0) use = false;
+      if (!use) continue;
+
+      double age_begin = m.age_begin;
+      if (age_begin < ref_age) age_begin = ref_age;
+      while (current_block_base + num_bases_per_block < bp_mut) {  // coal.cpp:2227-2234
+        current_block_base += num_bases_per_block;
+        advance_block();
+      }
+      // target genotype rounded to a diploid call, in float (coal.cpp:2236-2242)
+      float f_DAF_target = tgt.DAF, f_AAF_target = tgt.AAF;
+      f_DAF_target /= N_target / 2.0;
+      f_AAF_target /= N_target / 2.0;
+      f_DAF_target = std::round(f_DAF_target);
+      f_AAF_target = std::round(f_AAF_target);
+
+      std::vector<double>& sh = tab.sh[blk];
+      std::vector<double>& ns = tab.ns[blk];
+      const int DAF_ref = ref.DAF;
+      if (age_begin <= age) {  // coal.cpp:2245-2275
+        const int bin2 = age_bin_index(m.age_end, C);
+        if (bin2 < A) {  // row 0 of the A*A table; larger indices land in rows nobody reads
+          tab.sh_emp[blk][bin2] += f_DAF_target * DAF_ref / ((double)N_ref);
+          tab.ns_emp[blk][bin2] += f_AAF_target * DAF_ref / ((double)N_ref);
+        }
+        for (int j = 0; j < num_samples; j++) {
+          double sampled_age = dist_unif(rng) * (m.age_end - age_begin) + age_begin;
+          if (sampled_age < age) sampled_age = age;
+          const int bin = age_bin_index(sampled_age, C);
+          if (bin < A) ns[bin] += f_AAF_target * DAF_ref / ((double)N_ref * num_samples);
+        }
+      } else {  // coal.cpp:2277-2297
+        int j = 0;
+        while (j < num_samples) {
+          const double sampled_age = dist_unif(rng) * (m.age_end - age_begin) + age_begin;
+          bool skip = sampled_age < age;
+          const int bin = age_bin_index(sampled_age, C);
+          if (bin >= A) skip = true;
+          if (!skip) {
+            sh[bin] += f_DAF_target * DAF_ref / ((double)N_ref * num_samples);
+            ns[bin] += f_AAF_target * DAF_ref / ((double)N_ref * num_samples);
+            j++;
+          }
+        }
+      }
+    }
+    advance_block();  // chromosome end, coal.cpp:2306-2310
+  }
+  if (tgt.fp) std::fclose(tgt.fp);
+  if (ref.fp) std::fclose(ref.fp);
+  tab.sh.resize(num_blocks);
+  tab.ns.resize(num_blocks);
+  tab.sh_emp.resize(num_blocks);
+  tab.ns_emp.resize(num_blocks);
+  return num_blocks;
+}
+
+// OUT.colate_mat (coal.cpp:3471-3499): 185 grid values, then per replicate 185 shared
+// and 185 not-shared counts, read with operator>> (a failed extraction leaves zeros).
+bool load_colate_mat(const std::string& path, int B, int A, std::vector<double>& grid,
+                     std::vector<double>& csh, std::vector<double>& cns) {
+  GzText is;
+  if (!is.open(path)) return false;
+  std::string all, line;
+  while (is.getline(line)) {
+    all += line;
+    all += '\n';
+  }
+  std::istringstream ss(all);
+  for (int b = 0; b < A; b++) ss >> grid[b];
+  csh.assign((size_t)B * A, 0.0);
+  cns.assign((size_t)B * A, 0.0);
+  for (int i = 0; i < B; i++) {
+    for (int b = 0; b < A; b++) ss >> csh[(size_t)i * A + b];
+    for (int b = 0; b < A; b++) ss >> cns[(size_t)i * A + b];
+  }
+  return true;
+}
+
+bool file_exists(const std::string& p) {
+  FILE* f = std::fopen(p.c_str(), "rb");
+  if (!f) return false;
+  std::fclose(f);
+  return true;
+}
+
+int run_mut(const Options& opt) {
+  if (!opt.has("mut") || !opt.has("output")) {  // coal.cpp:3077-3087
+    std::cout << "Not enough arguments supplied." << std::endl;
+    std::cout << "Needed: mut, bins, output. Optional: target_tmp, reference_tmp, target_age, "
+                 "reference_age, target_mask, reference_mask, coal, num_bootstrap."
+              << std::endl;
+    print_help();
+    return 0;
+  }
+  std::cerr << "---------------------------------------------------------" << std::endl;
+  std::cerr << "Calculating coalescence rates for (ancient) samples.." << std::endl;
+
+  double target_age = 0, ref_age = 0;
+  try {
+    if (opt.has("target_age")) target_age = std::stof(opt.get("target_age"));
+    if (opt.has("reference_age")) ref_age = std::stof(opt.get("reference_age"));
+  } catch (...) {
+    std::cerr << "Error: sample ages must be numbers." << std::endl;
+    return 1;
+  }
+  if (!(target_age >= 0.0) || !(ref_age >= 0.0)) {
+    std::cerr << "Error: sample ages must be non-negative." << std::endl;
+    return 1;
+  }
+  double years_per_gen = 28.0;
+  if (opt.has("years_per_gen")) years_per_gen = std::stof(opt.get("years_per_gen"));
+  const double age = std::max(target_age, ref_age) / years_per_gen;
+  std::cerr << age << std::endl;
+  const bool is_ancient = age > 0.0;
+
+  const double C = 10;
+  std::vector<double> age_grid(256);
+  const int A = colate_age_grid(age_grid.data(), 256);
+  age_grid.resize(A);
+  std::cerr << "num_bins: " << A << std::endl;
+
+  const int num_bases_per_block = 30e6;
+  std::mt19937 rng;
+  int seed = std::time(0) + getpid();  // coal.cpp:3158
+  if (opt.has("seed")) seed = std::stoi(opt.get("seed"));
+  rng.seed(seed);
+  int B = 1;
+  if (opt.has("num_bootstraps")) B = std::stoi(opt.get("num_bootstraps"));
+  if (B < 1) {
+    std::cerr << "Error: --num_bootstraps must be at least 1." << std::endl;
+    return 1;
+  }
+  const std::string out = opt.get("output");
+
+  std::vector<double> csh, cns;
+  const std::string mat = out + ".colate_mat";
+  if (file_exists(mat)) {  // coal.cpp:3169-3170, 3471-3499
+    std::cerr << "Loading precomputed file " << mat << std::endl;
+    load_colate_mat(mat, B, A, age_grid, csh, cns);
+  } else if (opt.has("target_tmp") && opt.has("reference_tmp")) {
+    std::vector<std::string> mut_files, tmask, rmask, names;
+    if (opt.has("chr")) {  // coal.cpp:3295-3310
+      GzText is_chr;
+      if (!is_chr.open(opt.get("chr")))
+        std::cerr << "Error while opening file " << opt.get("chr") << std::endl;
+      std::string line;
+      while (is_chr.getline(line)) {
+        names.push_back(line);
+        mut_files.push_back(opt.get("mut") + "_chr" + line + ".mut");
+        if (opt.has("target_mask")) tmask.push_back(opt.get("target_mask") + "_chr" + line + ".fa");
+        if (opt.has("reference_mask")) rmask.push_back(opt.get("reference_mask") + "_chr" + line + ".fa");
+      }
+    } else {
+      names.push_back("");
+      mut_files.push_back(opt.get("mut"));
+      if (opt.has("target_mask")) tmask.push_back(opt.get("target_mask"));
+      if (opt.has("reference_mask")) rmask.push_back(opt.get("reference_mask"));
+    }
+    BlockTables tab;
+    const int nb = fill_tables_from_tmp(names, mut_files, opt.get("target_tmp"),
+                                        opt.get("reference_tmp"), tmask, rmask, C, rng,
+                                        num_bases_per_block, A, tab);
+    std::cerr << "Number of blocks: " << nb << std::endl;
+    if (nb < 1) {
+      std::cerr << "Error: no genome blocks were read." << std::endl;
+      return 1;
+    }
+    // block bootstrap + F redistribution (coal.cpp:3326-3451) on flat [nb][A] tables
+    std::vector<double> fsh((size_t)nb * A), fns((size_t)nb * A), fshe((size_t)nb * A), fnse((size_t)nb * A);
+    for (int j = 0; j < nb; j++) {
+      std::copy(tab.sh[j].begin(), tab.sh[j].end(), fsh.begin() + (size_t)j * A);
+      std::copy(tab.ns[j].begin(), tab.ns[j].end(), fns.begin() + (size_t)j * A);
+      std::copy(tab.sh_emp[j].begin(), tab.sh_emp[j].end(), fshe.begin() + (size_t)j * A);
+      std::copy(tab.ns_emp[j].begin(), tab.ns_emp[j].end(), fnse.begin() + (size_t)j * A);
+    }
+    csh.assign((size_t)B * A, 0.0);
+    cns.assign((size_t)B * A, 0.0);
+    if (int rc = colate_bootstrap_counts(&rng, B, nb, A, age_grid.data(), age, fsh.data(), fns.data(),
+                                         fshe.data(), fnse.data(), csh.data(), cns.data())) {
+      std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
+      return 1;
+    }
+  } else {
+    std::cerr << "Error: colate_amd reads --target_tmp/--reference_tmp (.colate.in) inputs or an "
+                 "existing <output>.colate_mat; BCF/BAM inputs go through `Colate --mode make_tmp` first."
+              << std::endl;
+    return 1;
+  }
+
+  // ---- epochs (coal.cpp:3501-3646)
+  std::vector<double> epochs(COLATE_MAX_EPOCHS), init_rates(COLATE_MAX_EPOCHS, COLATE_DEFAULT_INIT_RATE);
+  int E = 0, ep_null = 0;
+  if (opt.has("coal")) {
+    E = colate_epochs_from_coal(opt.get("coal").c_str(), age, epochs.data(), init_rates.data(), COLATE_MAX_EPOCHS);
+    if (E > 0) {
+      for (int e = 0; e < E; e++) std::cerr << init_rates[e] << " ";
+      std::cerr << std::endl;
+    }
+  } else if (opt.has("bins")) {
+    E = colate_epochs_from_bins(opt.get("bins").c_str(), age, years_per_gen, epochs.data(), COLATE_MAX_EPOCHS, &ep_null);
+  } else {
+    std::cerr << "Error: need --bins or --coal." << std::endl;
+    return 1;
+  }
+  if (E <= 0) {
+    std::cerr << colate_last_error() << std::endl;
+    return 1;
+  }
+  epochs.resize(E);
+  init_rates.resize(E);
+
+  std::cerr << "Maximising likelihood using EM.. " << std::endl;
+  if (opt.has("device")) {
+    if (int rc = colate_set_device(std::stoi(opt.get("device")))) {
+      std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
+      return 1;
+    }
+  }
+  std::vector<double> rates((size_t)B * E), ll(B);
+  std::vector<int> iters(B), flags(B);
+  int rc = colate_em_batch(B, E, A, age_grid.data(), csh.data(), cns.data(), epochs.data(),
+                           init_rates.data(), COLATE_DEFAULT_MAX_ITER, COLATE_DEFAULT_MIN_ITER,
+                           COLATE_DEFAULT_REL_TOL, COLATE_DEFAULT_RATE_FLOOR, rates.data(),
+                           iters.data(), ll.data(), flags.data());
+  if (rc) {
+    std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
+    return 1;
+  }
+  for (int i = 0; i < B; i++) {
+    std::cerr << "Bootstrap " << i + 1 << ": Total iterations " << iters[i] << std::endl;
+    if (flags[i] & (COLATE_FLAG_NAN | COLATE_FLAG_NEG))
+      std::cerr << "Warning: bootstrap " << i + 1
+                << " produced NaN or negative sufficient statistics (the reference aborts here)."
+                << std::endl;
+  }
+  if (colate_write_coal((out + ".coal").c_str(), B, E, epochs.data(), rates.data(), is_ancient ? 1 : 0, ep_null)) {
+    std::cerr << "Error: " << colate_last_error() << std::endl;
+    return 1;
+  }
+
+  rusage usage;  // coal.cpp:3852-3861
+  getrusage(RUSAGE_SELF, &usage);
+  std::cerr << "CPU Time spent: " << usage.ru_utime.tv_sec << "." << std::setfill('0') << std::setw(6)
+            << usage.ru_utime.tv_usec << "s; Max Memory usage: " << usage.ru_maxrss / 1000.0 << "Mb." << std::endl;
+  std::cerr << "---------------------------------------------------------" << std::endl << std::endl;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int colate_mut_main(int argc, char** argv) {
+  Options opt;
+  std::string err;
+  if (!parse_options(argc, argv, opt, err)) {
+    std::cerr << err << std::endl;
+    return 1;
+  }
+  if (!opt.has("mode")) {  // Colate.cpp:104-112
+    std::cout << "Not enough arguments supplied." << std::endl;
+    print_help();
+    return 0;
+  }
+  const std::string& mode = opt.get("mode");
+  if (mode == "mut") {
+    if (opt.has("help")) {
+      print_help();
+      std::cout << "Calculate coalescence rates for sample." << std::endl;
+      return 0;
+    }
+    try {
+      return run_mut(opt);
+    } catch (const std::exception& e) {
+      std::cerr << "Error: " << e.what() << std::endl;
+      return 1;
+    }
+  }
+  std::cout << "####### error #######" << std::endl;
+  std::cout << "colate_amd implements --mode mut only (preprocess_mut, make_tmp, calc_depth, "
+               "print_tmp, CondCoalRates stay with the reference build)."
+            << std::endl;
+  return 1;
+}

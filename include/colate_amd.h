@@ -1,0 +1,140 @@
+/* include/colate_amd.h -- C ABI of libcolate_amd.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE path of leospeidel/Colate: `Colate --mode mut` on
+ * precomputed .colate.in inputs, i.e. the block-bootstrap driver and the EM loop
+ * that turns age-binned shared / not-shared mutation counts into pairwise
+ * coalescence rates.  The reference has no FFI; its de-facto boundary is the C++
+ * class `coal_EM` (include/coal/coal_EM.hpp:14-63) used at exactly one site,
+ * include/coal/coal.cpp:3698-3721, inside the per-replicate EM loop
+ * include/coal/coal.cpp:3675-3827.  Calling a GPU once per age bin would be
+ * meaningless, so the replacement boundary is one coarse call per batch of
+ * bootstrap replicates (colate_em_batch), plus the single E-step
+ * (colate_em_estep) that corresponds to one pass of coal.cpp:3698-3733.
+ * INTEGRATION.md shows the patch a maintainer would apply to coal.cpp.
+ *
+ * Conventions: plain pointers and sizes, row-major, IEEE double; caller owns
+ * every buffer; the library keeps no state between calls besides the selected
+ * device.  Every function returns 0 on success or a negative COLATE_E* code and
+ * never aborts; colate_last_error() gives a message.  "_device" variants take
+ * pointers to device (HBM) memory and enqueue on a HIP stream without
+ * synchronising; the plain variants take host pointers and are synchronous.
+ * There is NO CPU fallback: without a usable HIP device the compute entry
+ * points fail with COLATE_ENODEVICE.
+ */
+#ifndef COLATE_AMD_H
+#define COLATE_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COLATE_OK 0
+#define COLATE_EINVAL (-1)    /* bad argument (sizes, NULL, unsorted grids, ...) */
+#define COLATE_ENODEVICE (-2) /* no usable HIP device                            */
+#define COLATE_EHIP (-3)      /* a HIP runtime call failed                       */
+#define COLATE_ELIMIT (-4)    /* E or A above the compiled limits (256 each)     */
+#define COLATE_EIO (-5)       /* file could not be read / written                */
+
+/* per-replicate flags in out_flags[]: conditions on which the reference aborts
+ * through assert() (coal.cpp:3711-3714, coal_EM.cpp:128-129, 351) or that it
+ * cannot report (iteration cap) */
+#define COLATE_FLAG_NAN 1
+#define COLATE_FLAG_NEG 2
+#define COLATE_FLAG_MAXITER 4
+
+/* compiled limits of the EM kernel: one epoch / one age bin per thread of a 256-thread workgroup */
+#define COLATE_MAX_EPOCHS 256
+#define COLATE_MAX_AGE_BINS 256
+
+/* reference defaults (coal.cpp:3656, 3822, 3798-3803, 3636) */
+#define COLATE_DEFAULT_MAX_ITER 100000
+#define COLATE_DEFAULT_MIN_ITER 1000
+#define COLATE_DEFAULT_REL_TOL 1e-7
+#define COLATE_DEFAULT_RATE_FLOOR 5e-9
+#define COLATE_DEFAULT_INIT_RATE (1.0 / 20000.0)
+
+const char* colate_version(void);
+const char* colate_last_error(void);
+int colate_device_count(void);       /* >= 0, or COLATE_ENODEVICE */
+int colate_set_device(int ordinal);  /* device used by the calling thread's later calls */
+
+/* ---- the EM hot path ------------------------------------------------------
+ * Replaces coal.cpp:3675-3827 (bootstrap EM driver: coal_EM construction,
+ * EM_shared/EM_notshared per age bin, accumulation, M-step, floor, stop rule)
+ * for B replicates at once.
+ *   age_grid[A]            ascending age-bin representatives (coal.cpp:3126-3137; A = 185)
+ *   cnt_shared[B][A], cnt_notshared[B][A]   bootstrap count tables (coal.cpp:3344-3451)
+ *   epochs[E]              epoch starts in generations, epochs[0] <= age_grid[0], non-decreasing
+ *   init_rates[E]          starting rates (coal.cpp:3636-3646)
+ *   max_iter, min_iter, rel_tol, rate_floor   100000, 1000, 1e-7, 5e-9 in the reference
+ *   out_rates[B][E], out_iters[B] (the reference's "Total iterations"), out_loglik[B], out_flags[B]
+ */
+int colate_em_batch(int B, int E, int A, const double* age_grid, const double* cnt_shared,
+                    const double* cnt_notshared, const double* epochs, const double* init_rates,
+                    int max_iter, int min_iter, double rel_tol, double rate_floor,
+                    double* out_rates, int* out_iters, double* out_loglik, int* out_flags);
+
+/* Same, all pointers in device memory, asynchronous on `hip_stream` (a
+ * hipStream_t, NULL = default stream).  epochs_per_replicate / rates_per_replicate
+ * != 0 select [B][E] layouts for epochs / init_rates (batched all-pairs, where
+ * every (target, reference) pair brings its own epochs); 0 = one shared [E] row.
+ * Host-side argument checks that need the data (sortedness) are skipped. */
+int colate_em_batch_device(int B, int E, int A, const double* age_grid, const double* cnt_shared,
+                           const double* cnt_notshared, const double* epochs,
+                           int epochs_per_replicate, const double* init_rates,
+                           int rates_per_replicate, int max_iter, int min_iter, double rel_tol,
+                           double rate_floor, double* out_rates, int* out_iters,
+                           double* out_loglik, int* out_flags, void* hip_stream);
+
+/* One E-step = one pass of coal.cpp:3698-3733 for each of B replicates with the
+ * rates given per replicate: rates[B][E] -> num_acc[B][E], den_acc[B][E]
+ * (coal_rates_num / coal_rates_denom), loglik[B], flags[B]. */
+int colate_em_estep(int B, int E, int A, const double* age_grid, const double* cnt_shared,
+                    const double* cnt_notshared, const double* epochs, const double* rates,
+                    double* num_acc, double* den_acc, double* loglik, int* flags);
+int colate_em_estep_device(int B, int E, int A, const double* age_grid, const double* cnt_shared,
+                           const double* cnt_notshared, const double* epochs, const double* rates,
+                           double* num_acc, double* den_acc, double* loglik, int* flags,
+                           void* hip_stream);
+
+/* ---- host-side pieces of mut() around the hot path (CPU, no device needed) ----
+ * coal.cpp:3126-3137: the 185-point age grid.  Returns A or COLATE_EINVAL if cap < A. */
+int colate_age_grid(double* age_grid, int cap);
+
+/* coal.cpp:3551-3632: epochs from `--bins x,y,step` (std::stof semantics), with the
+ * ancient-sample rule; age = max(target_age, reference_age)/years_per_gen in
+ * generations.  Returns E (>0) or a negative code; *ep_null as coal.cpp:3622. */
+int colate_epochs_from_bins(const char* bins, double age, double years_per_gen, double* epochs,
+                            int cap, int* ep_null);
+
+/* coal.cpp:3508-3549 + 3638-3646: epochs and initial rates from a `--coal` file.
+ * Returns E or a negative code. */
+int colate_epochs_from_coal(const char* path, double age, double* epochs, double* init_rates,
+                            int cap);
+
+/* coal.cpp:3344-3451: block bootstrap.  Draws the multinomial block weights for
+ * num_bootstrap replicates from std::mt19937 state `rng_state` (opaque, from
+ * colate_rng_*), forms the weighted block sums and applies the F
+ * redistribution of the age_begin<=0 mutations.  Tables are [nb][A]; the emp
+ * tables hold row 0 of the reference's A*A tables (the only row it reads). */
+void* colate_rng_create(unsigned int seed); /* std::mt19937, coal.cpp:3157-3162 */
+void colate_rng_destroy(void* rng_state);
+int colate_bootstrap_counts(void* rng_state, int num_bootstrap, int nb, int A,
+                            const double* age_grid, double age, const double* sh_block,
+                            const double* ns_block, const double* sh_emp_block,
+                            const double* ns_emp_block, double* cnt_shared,
+                            double* cnt_notshared);
+
+/* coal.cpp:3660-3672, 3830-3847: the .coal text (6 significant digits, trailing blank). */
+int colate_write_coal(const char* path, int B, int E, const double* epochs, const double* rates,
+                      int is_ancient, int ep_null);
+
+/* The whole `Colate --mode mut` command line for the .colate.in / .colate_mat
+ * inputs (Colate.cpp:6-116 -> coal.cpp:3071-3863): same option names, same
+ * stderr progress lines, same .coal output.  Returns the process exit code. */
+int colate_mut_main(int argc, char** argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLATE_AMD_H */

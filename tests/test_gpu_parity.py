@@ -1,0 +1,134 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle on the same inputs.
+
+Tolerances (north_star): rates within 1e-6 relative; here the E-step statistics and the
+rates are held to much tighter bounds wherever the reference's own arithmetic is
+well-conditioned (see oracle_lib.stable_mask and DESIGN.md §6 for the one exception)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+RATE_RTOL = 1e-6  # north_star tolerance on rates
+
+
+def _rel(a, b):
+    m = np.maximum(np.abs(a), np.abs(b))
+    m[m == 0] = 1.0
+    return np.abs(a - b) / m
+
+
+def _den_tol(D0, ep, total_count):
+    """Tolerance for E-step denominators: 1e-6 relative, plus the rounding residue the reference
+    itself carries: its `integ = 1 - num[0] - num[1] - ...` (coal_EM.cpp:270-274, 445-449) sums
+    terms exp(A - Z) whose relative error is ~1e-16*|A - Z| (hundreds at high rates), so integ is
+    exact only to ~1e-14 absolute, and it enters denom[e] multiplied by the epoch length
+    (DESIGN.md §6).  1e-13 * dt is that residue's scale, not a slack on real signal."""
+    dt = np.append(np.diff(ep), 0.0)
+    return 1e-6 * np.abs(D0) + 1e-13 * dt * total_count + 1e-300
+
+
+@pytest.fixture(scope="module")
+def ca():
+    import colate_amd
+
+    assert colate_amd.device_count() >= 1
+    return colate_amd
+
+
+@pytest.mark.parametrize("bins", ["3,7,0.2", "2,7.95,0.05"])
+def test_estep_matches_oracle(ca, bins):
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins(bins)
+    E, A = ep.size, grid.size
+    rng = np.random.default_rng(7)
+    B = 24
+    rates = np.zeros((B, E))
+    csh = np.zeros((B, A))
+    cns = np.zeros((B, A))
+    for t in range(B):
+        if t < 5:
+            rates[t] = 1e-6 * 10 ** t
+        else:
+            rates[t] = np.exp(rng.uniform(np.log(1e-6), np.log(1e-3), E))
+            if t % 3 == 0:
+                rates[t, : rng.integers(1, 4)] = 0.0
+            if t % 4 == 0:
+                rates[t, rng.integers(0, E, 3)] = 5e-9
+        csh[t] = np.where(rng.uniform(size=A) < 0.8, rng.uniform(0, 50, A), 0.0)
+        cns[t] = np.where(rng.uniform(size=A) < 0.8, rng.uniform(0, 500, A), 0.0)
+        if t % 2:
+            csh[t, :40] = cns[t, :40] = 0
+            csh[t, 151:] = cns[t, 151:] = 0
+    num, den, ll, flags = ca.em_estep(grid, csh, cns, ep, rates)
+    checked = 0
+    for t in range(B):
+        N0, D0, ll0, fl0 = ol.estep(ep, rates[t], grid, csh[t], cns[t])
+        if fl0:  # the reference aborts on this input (assert !isnan, coal.cpp:3711): nothing to compare
+            continue
+        checked += 1
+        assert flags[t] == 0
+        assert abs(ll[t] - ll0) <= 1e-12 * abs(ll0)
+        assert _rel(num[t], N0).max() < 1e-8
+        assert (np.abs(den[t] - D0) <= _den_tol(D0, ep, csh[t].sum() + cns[t].sum())).all()
+    assert checked >= B - 2
+
+
+def test_em_matches_oracle_wholegenome_like(ca):
+    from colate_amd import workloads
+
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins("3,7,0.2")
+    csh, cns = workloads.bootstrap_tables(grid, 6)
+    r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep)
+    r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep)
+    assert (fl0 == 0).all() and (fl1 == 0).all()
+    assert (it0 == it1).all()
+    assert np.allclose(ll1, ll0, rtol=1e-12, atol=0)
+    assert _rel(r1, r0).max() < RATE_RTOL
+    assert _rel(r1, r0).max() < 1e-9  # what we actually get
+
+
+def test_em_matches_oracle_122_epochs(ca):
+    from colate_amd import workloads
+
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins("2,7.95,0.05")
+    csh, cns = workloads.bootstrap_tables(grid, 3, nb=9, scale=1.0)
+    r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep)
+    r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep)
+    assert (it0 == it1).all()
+    assert np.allclose(ll1, ll0, rtol=1e-12, atol=0)
+    mask = ol.stable_mask(grid, csh, cns, ep, r0)
+    assert mask.mean() > 0.85  # only the far tail is undetermined in the reference
+    assert _rel(r1, r0)[mask].max() < RATE_RTOL
+
+
+def test_coal_EM_mirror_reference_unit_test(ca):
+    """Restates TEST_CASE("test EM expectation step") (include/test/test_aDNA.cpp:68-212) with the
+    GPU class in place of coal_EM and the oracle in place of coal_EM_simplified, at 1e-9 instead of
+    the reference test's 10 %."""
+    E = 21
+    ypg = np.float32(28.0)
+    ep = np.zeros(E)
+    ep[1] = 1e3 / 28.0
+    log10 = float(np.float32(np.log(10)))
+    for e in range(2, E - 1):
+        ep[e] = np.exp(log10 * (3.0 + 4.0 * (e - 1.0) / (E - 3.0))) / 28.0
+    ep[E - 1] = 1e8 / 28.0
+    C = 5
+    nb = int(np.log(1e8) * C)
+    ages = np.exp(np.arange(nb) / C) / 10.0
+    for f in range(1, 8):
+        rate = 1e-7 * np.exp(np.log(10) * (f - 1))
+        rates = np.full(E, rate)
+        em = ca.coal_EM(ep, rates)
+        for kind, shared in ((0, True), (1, False)):
+            num, den, ll, flags = em.EM_many(ages, shared)
+            for b, a in enumerate(ages):
+                l0, n0, d0 = ol.em_call(kind, ep, rates, a)
+                assert abs(ll[b] - l0) < 1e-9 * max(1.0, abs(l0))
+                assert np.all(num[b] >= 0) and np.all(den[b] >= 0)
+                assert _rel(num[b], n0).max() < 1e-7
+                assert (np.abs(den[b] - d0) <= _den_tol(d0, ep, 1.0)).all()
