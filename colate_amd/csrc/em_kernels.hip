@@ -7,10 +7,19 @@
 //   E-step accumulation            include/coal/coal.cpp:3704-3733
 //   M-step, floor, stop rule       include/coal/coal.cpp:3771-3815, 3822-3825
 //
-// One workgroup (256 threads, one wave per SIMD of a CU) owns one replicate and
-// runs all of its EM iterations inside one launch: counts, age grid, epochs and
-// the current rates never leave the CU (registers + LDS), so HBM sees each
-// replicate's 2*A counts once on the way in and E rates on the way out.
+// One workgroup owns one replicate and runs all of its EM iterations inside one
+// launch: counts, age grid, epochs and the current rates never leave the CU
+// (registers + LDS), so HBM sees each replicate's 2*A counts once on the way in
+// and E rates on the way out.  Each iteration is a short dependent chain, so
+// the kernel is built for LATENCY (BASELINE configs put <= 256 replicates on a
+// 256-CU GPU: one workgroup per CU):
+//
+//  * every wave of the workgroup carries the whole epoch state redundantly
+//    (epoch e in lane e & 63, chunk e >> 6), so the epoch-level recurrences are
+//    wave-local DPP scans and no barrier separates them from the bin phase;
+//  * age bins are one per thread; their per-epoch sums are reduced in registers
+//    (row-segmented DPP) and handed to the epoch lanes through a double-buffered
+//    LDS tile: ONE workgroup barrier per EM iteration.
 //
 // The reference evaluates exp(log-term - Z) for every (age bin, epoch) pair:
 // O(A*E) transcendentals per iteration.  Here every such term is factored into
@@ -21,14 +30,6 @@
 // operand (no fused multiply-add: this file is built with -ffp-contract=off and
 // uses fma only inside em_math.hpp and in recurrences that have no counterpart
 // in the reference).
-//
-// Phases of one iteration (threads change role between barriers):
-//   P1  epoch e : cs_e (sequential sum, as coal_EM.cpp:100-103), q_e, S_e, p_e, beta_e, W_e, V_e
-//   P2  epoch e : PW_e = sum_{j<e} W_j,  G_e = p_e + q_e G_{e+1}
-//   P3  bin b   : shared / not-shared bin terms  -> 8 per-bin values, ll partial
-//   P4  (e,arr) : per-epoch sums of the 8 per-bin values over the bins inside epoch e
-//   P5  epoch e : suffix sums over later epochs, forward recurrence T, N_e, D_e, M-step candidate
-//   P6  epoch e : resolve "num == 0 -> copy previous rate" chain, stop rule
 #include <hip/hip_runtime.h>
 
 #include "em_kernels.h"
@@ -36,86 +37,143 @@
 
 namespace {
 
-constexpr int kThreads = COLATE_EM_THREADS;
-constexpr int kNumBinArrays = 8;
-enum { O_G = 0, O_GC, O_GW, O_GV, O_H, O_HC, O_HN, O_HD };
+constexpr int kWave = 64;
+enum { O_G = 0, O_GC, O_H, O_HC, O_N, O_D, kNumBinArrays };            // per-bin values -> epochs
+enum { G_LAM = 0, G_INV, G_CS, G_S, G_XA, G_PW, kNumGather };           // per-epoch values -> bins
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// ----------------------------------------------------------------- lane plumbing
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// DPP move of a double.  Lanes whose source is out of range, or whose row is
+// not in ROW_MASK, keep `old` (BOUND == false) or read 0 (BOUND == true).
+template <int CTRL, int ROW_MASK = 0xf, bool BOUND = false>
+__device__ __forceinline__ double dpp_d(double old, double v) {
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, BOUND);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, BOUND);
+  return __hiloint2double(hi, lo);
+}
+constexpr int ROW_SHR1 = 0x111, ROW_SHR2 = 0x112, ROW_SHR4 = 0x114, ROW_SHR8 = 0x118;
+constexpr int ROW_SHL1 = 0x101, ROW_SHL2 = 0x102, ROW_SHL4 = 0x104, ROW_SHL8 = 0x108;
+constexpr int ROW_BCAST15 = 0x142, ROW_BCAST31 = 0x143, WAVE_SHR1 = 0x138, WAVE_SHL1 = 0x130;
+
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ double wave_prefix_sum(double v) {
+  v += dpp_d<ROW_SHR1>(0.0, v);
+  v += dpp_d<ROW_SHR2>(0.0, v);
+  v += dpp_d<ROW_SHR4>(0.0, v);
+  v += dpp_d<ROW_SHR8>(0.0, v);
+  v += dpp_d<ROW_BCAST15, 0xa>(0.0, v);
+  v += dpp_d<ROW_BCAST31, 0xc>(0.0, v);
   return v;
+}
+// inclusive suffix sum over the 64 lanes (lane l: sum of lanes l..63)
+__device__ __forceinline__ double wave_suffix_sum(double v, int lane) {
+  v += dpp_d<ROW_SHL1>(0.0, v);
+  v += dpp_d<ROW_SHL2>(0.0, v);
+  v += dpp_d<ROW_SHL4>(0.0, v);
+  v += dpp_d<ROW_SHL8>(0.0, v);
+  const double r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
+  const double s23 = r2 + r3, s123 = r1 + s23;
+  const int row = lane >> 4;
+  const double add = row == 0 ? s123 : (row == 1 ? s23 : (row == 2 ? r3 : 0.0));
+  return v + add;
+}
+// inclusive prefix composition of the affine maps x -> a*x + b (lane order = application order):
+// afterwards (a, b) of lane l is f_l o ... o f_0
+__device__ __forceinline__ void wave_affine_scan(double& a, double& b) {
+#define COLATE_AFF_STEP(CTRL, RM)                  \
+  {                                                \
+    const double as = dpp_d<CTRL, RM>(1.0, a);     \
+    const double bs = dpp_d<CTRL, RM>(0.0, b);     \
+    b = em::fma_(a, bs, b);                        \
+    a = a * as;                                    \
+  }
+  COLATE_AFF_STEP(ROW_SHR1, 0xf)
+  COLATE_AFF_STEP(ROW_SHR2, 0xf)
+  COLATE_AFF_STEP(ROW_SHR4, 0xf)
+  COLATE_AFF_STEP(ROW_SHR8, 0xf)
+  COLATE_AFF_STEP(ROW_BCAST15, 0xa)
+  COLATE_AFF_STEP(ROW_BCAST31, 0xc)
+#undef COLATE_AFF_STEP
 }
 
 __device__ __forceinline__ bool finite_pos(double x) { return x > 0.0 && x < __builtin_inf(); }
 
-template <int MODE>  // 0: EM to convergence, 1: one E-step (num/den/ll out)
-__global__ __launch_bounds__(kThreads) void em_kernel(ColateEmArgs p) {
+// wave-local LDS hand-off: earlier ds_writes of this wave are visible to its later ds_reads
+// (the LDS queue is in order per wave); this only stops the compiler from moving them.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// MODE 0: EM to convergence, 1: one E-step (num/den/ll out).  NCH = epoch chunks of 64 per lane.
+template <int MODE, int NCH>
+__global__ __launch_bounds__(COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
   extern __shared__ double lds[];
   const int E = p.E, A = p.A;
-  const int EP = E + 1;
-  const int AP = (A + 63) & ~63;
-  // ---- LDS carve-up (doubles) ----
-  double* s_t = lds;             // [EP] epoch starts
-  double* s_x = s_t + EP;        // [EP] lambda_e * dt_e
-  double* s_cs = s_x + EP;       // [EP] cumulative hazard at epoch start
-  double* s_lam = s_cs + EP;     // [EP]
-  double* s_inv = s_lam + EP;    // [EP] 1/lambda
-  double* s_q = s_inv + EP;      // [EP] exp(-x_e)
-  double* s_p = s_q + EP;        // [EP] 1-q (0 if epoch invalid); last epoch: 1 or 0
-  double* s_S = s_p + EP;        // [EP] exp(-cs_e)
-  double* s_W = s_S + EP;        // [EP] exp(A_ep) = S p
-  double* s_Xa = s_W + EP;       // [EP] (t_e + inv)/inv
-  double* s_PW = s_Xa + EP;      // [EP] prefix sums of W
-  double* s_G = s_PW + EP;       // [EP] relative suffix mass, s_G[E] = 0
-  double* s_cand = s_G + EP;     // [EP] M-step candidate rate
-  double* s_gs = s_cand + EP;    // [8][EP] per-epoch sums of the per-bin values
-  double* s_out = s_gs + kNumBinArrays * EP;  // [8][AP] per-bin values
-  double* s_ll = s_out + kNumBinArrays * AP;  // [4] per-wave log-likelihood partials
-  int* s_kb = reinterpret_cast<int*>(s_ll + 4);  // [AP] epoch of each bin
-  int* s_lo = s_kb + AP;                         // [EP] first bin of epoch e (clipped)
-  int* s_hi = s_lo + EP;                         // [EP] one past last bin of epoch e (clipped)
-  int* s_copy = s_hi + EP;                       // [EP] M-step: num == 0 -> copy previous
-  int* s_misc = s_copy + EP;                     // [4] nzlo, nzhi, flags
-
-  const int tid = threadIdx.x;
+  constexpr int EPAD = NCH * kWave;
+  const int AP = blockDim.x;  // A rounded up to a multiple of 64
+  const int nwaves = AP >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rep = blockIdx.x;
-  const bool is_ep = tid < E;
-  const bool is_bin = tid < A;
+
+  // ---- LDS carve-up ----
+  double* s_t = lds;                                            // [EPAD + 1] epoch starts
+  double* s_ep = s_t + EPAD + 1;                                // [nwaves][kNumGather][EPAD] per-wave epoch values
+  double* s_out = s_ep + nwaves * kNumGather * EPAD;            // [2][kNumBinArrays][AP] per-bin tails
+  double* s_ll = s_out + 2 * kNumBinArrays * AP;                // [2][4] per-wave log-likelihood partials
+  int* s_kb = reinterpret_cast<int*>(s_ll + 8);                 // [AP + 1] epoch of each bin
+  int* s_misc = s_kb + AP + 1;                                  // [4] nzlo, nzhi, flags
+  double* my_ep = s_ep + wave * kNumGather * EPAD;
 
   // ------------------------------------------------------------------ prologue
   const double* epochs = p.epochs + (size_t)rep * p.epochs_stride;
-  if (is_ep) s_t[tid] = epochs[tid];
+  for (int i = tid; i < EPAD + 1; i += AP) s_t[i] = (i < E) ? epochs[i] : 0.0;
   if (tid == 0) {
-    s_t[E] = 0.0;
     s_misc[0] = A;
     s_misc[1] = 0;
     s_misc[2] = 0;
   }
-  if (tid < 4) s_ll[tid] = 0.0;
-  for (int i = tid; i < kNumBinArrays * AP; i += kThreads) s_out[i] = 0.0;
+  if (tid < 8) s_ll[tid] = 0.0;
+  for (int i = tid; i < 2 * kNumBinArrays * AP; i += AP) s_out[i] = 0.0;
   __syncthreads();
 
-  // epoch-role statics
-  double t_e = 0, tn_e = 0, dt_e = 0, lam_e = 0;
-  bool valid_static = false;
-  if (is_ep) {
-    t_e = s_t[tid];
-    if (tid < E - 1) {
-      tn_e = s_t[tid + 1];
-      dt_e = tn_e - t_e;
-      valid_static = (tn_e != 0) && (dt_e > 0);  // coal_EM.cpp:117
-    } else {
-      valid_static = true;
+  // epoch-role statics (identical in every wave)
+  double t_e[NCH], tn_e[NCH], dt_e[NCH], lam_e[NCH];
+  bool vstat[NCH], ep_on[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const int e = c * kWave + lane;
+    ep_on[c] = e < E;
+    t_e[c] = s_t[e];
+    tn_e[c] = 0.0;
+    dt_e[c] = 0.0;
+    vstat[c] = false;
+    lam_e[c] = 0.0;
+    if (ep_on[c]) {
+      if (e < E - 1) {
+        tn_e[c] = s_t[e + 1];
+        dt_e[c] = tn_e[c] - t_e[c];
+        vstat[c] = (tn_e[c] != 0) && (dt_e[c] > 0);  // coal_EM.cpp:117
+      } else {
+        vstat[c] = true;
+      }
+      lam_e[c] = p.rates_in[(size_t)rep * p.rates_stride + e];
     }
-    lam_e = p.rates_in[(size_t)rep * p.rates_stride + tid];
   }
   // bin-role statics
+  const bool is_bin = tid < A;
   double a_b = 0, csh = 0, cns = 0, tk = 0, tkn = 0, dtk = 0, da = 0, db = 0;
-  int kb = 0;
+  int kb = E;  // padding lanes: beyond every epoch
   if (is_bin) {
     a_b = p.age_grid[tid];
-    double c1 = p.cnt_sh[(size_t)rep * A + tid];
-    double c2 = p.cnt_ns[(size_t)rep * A + tid];
+    const double c1 = p.cnt_sh[(size_t)rep * A + tid];
+    const double c2 = p.cnt_ns[(size_t)rep * A + tid];
     csh = (c1 > 0) ? c1 : 0.0;  // coal.cpp:3706, 3719: only counts > 0 are visited
     cns = (c2 > 0) ? c2 : 0.0;
     kb = E - 1;  // coal_EM.cpp:60-95: largest e with epochs[e] <= age (strict `age < epochs[e]`)
@@ -133,28 +191,54 @@ __global__ __launch_bounds__(kThreads) void em_kernel(ColateEmArgs p) {
     }
     da = a_b - tk;
     db = tkn - a_b;
-    s_kb[tid] = kb;
     if (csh > 0 || cns > 0) {
       atomicMin(&s_misc[0], tid);
       atomicMax(&s_misc[1], tid + 1);
     }
   }
+  s_kb[tid] = kb;
+  if (tid == 0) s_kb[AP] = E + 1;
   __syncthreads();
-  if (is_ep) {
-    int lo = A, hi = 0;
-    for (int b = 0; b < A; b++) {
-      if (s_kb[b] == tid) {
-        if (b < lo) lo = b;
-        hi = b + 1;
+  const bool bin_live = is_bin && (csh > 0 || cns > 0);
+  const bool last_bin = (kb == E - 1);
+  // row-segmented reduction statics: f_d = 1 if the lane d to the left (same 16-lane row) is in
+  // the same epoch; a lane is the "tail" of its (row, epoch) run if its right neighbour is not
+  double f1 = 0, f2 = 0, f4 = 0, f8 = 0;
+  {
+    const int r = lane & 15;
+    if (r >= 1 && s_kb[tid - 1] == kb) f1 = 1.0;
+    if (r >= 2 && s_kb[tid - 2] == kb) f2 = 1.0;
+    if (r >= 4 && s_kb[tid - 4] == kb) f4 = 1.0;
+    if (r >= 8 && s_kb[tid - 8] == kb) f8 = 1.0;
+  }
+  const bool is_tail = is_bin && ((lane & 15) == 15 || s_kb[tid + 1] != kb);
+  // epoch-role: rows of the bin tile that hold tails of this epoch, clipped to the bins with data
+  int row_lo[NCH], row_hi[NCH], seg_hi[NCH];
+  {
+    const int nzlo = s_misc[0], nzhi = s_misc[1];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      const int e = c * kWave + lane;
+      int lo = A, hi = 0;
+      if (ep_on[c]) {
+        for (int b = 0; b < A; b++) {
+          if (s_kb[b] == e) {
+            if (b < lo) lo = b;
+            hi = b + 1;
+          }
+        }
+      }
+      seg_hi[c] = hi;
+      const int clo = lo > nzlo ? lo : nzlo, chi = hi < nzhi ? hi : nzhi;
+      if (clo < chi) {
+        row_lo[c] = clo >> 4;
+        row_hi[c] = (chi - 1) >> 4;
+      } else {
+        row_lo[c] = 1;
+        row_hi[c] = 0;
       }
     }
-    const int nzlo = s_misc[0], nzhi = s_misc[1];
-    if (lo < nzlo) lo = nzlo;
-    if (hi > nzhi) hi = nzhi;
-    s_lo[tid] = lo;
-    s_hi[tid] = hi;
   }
-  const bool bin_live = is_bin && (csh > 0 || cns > 0);
   int my_flags = 0;
 
   const double thr = 1.0 - p.rel_tol;
@@ -164,190 +248,294 @@ __global__ __launch_bounds__(kThreads) void em_kernel(ColateEmArgs p) {
 
   for (iter = 0; iter < max_iter; iter++) {
     const bool need_ll = (MODE == 1) || (iter >= p.min_iter) || (iter == max_iter - 1);
-    // ---------------------------------------------------------------- P1
-    if (is_ep) {
-      s_x[tid] = lam_e * dt_e;
-      s_lam[tid] = lam_e;
-    }
-    __syncthreads();
-    double q_e = 0, p_e = 0, beta_e = 0, W_e = 0, VW_e = 0;
-    if (is_ep) {
-      double cs = 0.0;  // cs_e = ((x_0 + x_1) + ...) + x_{e-1}, in this order
-      for (int j = 0; j < tid; j++) cs = cs + s_x[j];
-      const double csn = cs + lam_e * dt_e;
-      const double inv = 1.0 / lam_e;
-      const double S = em::em_exp(-cs);
-      const bool valid = valid_static && (lam_e > 0);
-      if (tid < E - 1) {
-        q_e = em::em_exp(-csn + cs);  // exp(-cumsum[i+1] + cumsum[i]), coal_EM.cpp:120
-        if (valid) {
-          p_e = 1.0 - q_e;                              // exp(A_ep + cs), coal_EM.cpp:119
-          beta_e = (t_e + inv) - (tn_e + inv) * q_e;    // exp(B_ep + cs), coal_EM.cpp:120
-        }
-      } else if (valid) {  // last epoch, coal_EM.cpp:136-141
-        p_e = 1.0;
-        beta_e = t_e + inv;
-      }
-      W_e = S * p_e;
-      VW_e = S * beta_e - t_e * W_e;
-      s_cs[tid] = cs;
-      s_inv[tid] = inv;
-      s_q[tid] = q_e;
-      s_p[tid] = p_e;
-      s_S[tid] = S;
-      s_W[tid] = W_e;
-      s_Xa[tid] = (t_e + inv) / inv;  // coal_EM.cpp:204
-    }
-    __syncthreads();
-    // ---------------------------------------------------------------- P2
-    double PWn_e = 0, Gn_e = 0;
-    if (is_ep) {
-      double pw = 0.0;
-      for (int j = 0; j < tid; j++) pw = pw + s_W[j];
-      double g = 0.0;
-      for (int j = E - 1; j > tid; j--) g = em::fma_(s_q[j], g, s_p[j]);
-      Gn_e = g;                          // G_{e+1}
-      s_PW[tid] = pw;                    // PW_e
-      PWn_e = pw + W_e;                  // PW_{e+1}
-      s_G[tid] = em::fma_(q_e, g, p_e);  // G_e
-      if (tid == 0) s_G[E] = 0.0;
-    }
-    __syncthreads();
-    // ---------------------------------------------------------------- P3
+    const int par = iter & 1;
+    // ============================================================ epoch phase (every wave)
+    double q_e[NCH], p_e[NCH], beta_e[NCH], W_e[NCH], VW_e[NCH], PWn_e[NCH], cs_e[NCH], csn_e[NCH];
     {
-      double llp = 0.0;
-      if (bin_live) {
-        double o_g = 0, o_gc = 0, o_gW = 0, o_gV = 0, o_h = 0, o_hc = 0, o_hN = 0, o_hD = 0;
-        const double lk = s_lam[kb], ik = s_inv[kb], ck = s_cs[kb];
-        const bool lpos = lk > 0;
-        const double ck1 = ck + lk * da;  // coal_EM.cpp:178-181 at the merged grid
-        if (csh > 0) {                    // ---- EM_shared, coal_EM.cpp:198-210, 263-287
-          const double Sk = s_S[kb];
-          const double qd = em::em_exp(-ck1 + ck);
-          double Wp = 0.0, Vp = 0.0;
-          if (lpos) {
-            Wp = Sk * (1.0 - qd);
-            const double X = s_Xa[kb] - (a_b + ik) / ik * qd;
-            Vp = X * ik * Sk;
-          }
-          const double Sig = s_PW[kb] + Wp;
-          if (finite_pos(Sig)) {
-            const double r = 1.0 / Sig;
-            const double nk = Wp * r;
-            double dk = Vp * r + (-tk * nk);
-            if (dk < 0.0) dk = 0.0;
-            o_g = csh * r;
-            o_gc = csh;
-            o_gW = csh * nk;
-            o_gV = csh * dk;
-            if (need_ll) llp += csh * em::em_log(Sig);
-          }
+      double x[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) x[c] = lam_e[c] * dt_e[c];
+      // cs_e = ((x_0 + x_1) + ...) + x_{e-1}, in this order (coal_EM.cpp:100-103)
+      double* cs = cs_e;
+      double run = 0.0;  // uniform running sum; lane j of chunk c snapshots it before x_j is added
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        cs[c] = 0.0;
+        const int jmax = (E - c * kWave) < kWave ? (E - c * kWave) : kWave;
+        for (int j = 0; j < jmax; j++) {
+          if (lane == j) cs[c] = run;
+          run = run + readlane_d(x[c], j);
         }
-        if (cns > 0) {  // ---- EM_notshared, coal_EM.cpp:330-357, 435-460
-          const double ck2 = ck1 + lk * (a_b - a_b);
-          if (kb < E - 1) {
-            const double ck3 = ck2 + lk * db;
-            const double u = em::em_exp(-ck3 + ck2);
-            double pn = 0.0, bn = 0.0;
-            if (lpos) {
-              pn = 1.0 - u;
-              bn = (a_b + ik) - (tkn + ik) * u;
-            }
-            const double Sig = pn + u * s_G[kb + 1];
-            if (finite_pos(Sig)) {
-              const double rr = 1.0 / Sig;
-              const double nk = pn * rr;
-              double dk = bn * rr + (-tk * nk + dtk * (1.0 - nk));
-              if (dk < 0.0) dk = 0.0;
-              o_h = cns * (u * rr);
-              o_hc = cns;
-              o_hN = cns * nk;
-              o_hD = cns * dk;
-              if (need_ll) llp += cns * (-ck2 + em::em_log(Sig));
-            }
+      }
+      double pw_carry = 0.0;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        const int e = c * kWave + lane;
+        const double csn = cs[c] + x[c];
+        csn_e[c] = csn;
+        const double inv = 1.0 / lam_e[c];
+        const double S = em::em_exp(-cs[c]);
+        const bool valid = vstat[c] && (lam_e[c] > 0);
+        q_e[c] = 0.0;
+        p_e[c] = 0.0;
+        beta_e[c] = 0.0;
+        if (e < E - 1) {
+          q_e[c] = em::em_exp(-csn + cs[c]);  // exp(-cumsum[i+1] + cumsum[i]), coal_EM.cpp:120
+          if (valid) {
+            p_e[c] = 1.0 - q_e[c];                                  // exp(A_ep + cs), coal_EM.cpp:119
+            beta_e[c] = (t_e[c] + inv) - (tn_e[c] + inv) * q_e[c];  // exp(B_ep + cs), coal_EM.cpp:120
+          }
+        } else if (e == E - 1 && valid) {  // last epoch, coal_EM.cpp:136-141
+          p_e[c] = 1.0;
+          beta_e[c] = t_e[c] + inv;
+        }
+        W_e[c] = ep_on[c] ? S * p_e[c] : 0.0;
+        VW_e[c] = ep_on[c] ? S * beta_e[c] - t_e[c] * W_e[c] : 0.0;
+        const double incl = wave_prefix_sum(W_e[c]);
+        const double pw = pw_carry + dpp_d<WAVE_SHR1, 0xf, true>(0.0, incl);  // PW_e = sum_{j<e} W_j
+        PWn_e[c] = pw + W_e[c];
+        pw_carry = pw_carry + readlane_d(incl, 63);
+        if (ep_on[c]) {
+          my_ep[G_LAM * EPAD + e] = lam_e[c];
+          my_ep[G_INV * EPAD + e] = inv;
+          my_ep[G_CS * EPAD + e] = cs[c];
+          my_ep[G_S * EPAD + e] = S;
+          my_ep[G_XA * EPAD + e] = (t_e[c] + inv) / inv;  // coal_EM.cpp:204
+          my_ep[G_PW * EPAD + e] = pw;
+        }
+      }
+    }
+    // G_e = sum_{j>=e} W_j / S_e (mass still to coalesce, relative to survival at t_e) obeys
+    // G_e = p_e + q_e G_{e+1} with p_e = 1 - q_e, i.e. 1 - G_e = (1 - G_{E-1}) prod q_j: it is 1
+    // whenever the last epoch can absorb (lambda_{E-1} > 0).  The reference asserts that
+    // (coal_EM.cpp:351) only for bins inside the last epoch; otherwise fall back to the product.
+    double lam_last = 0.0, cs_last = 0.0;  // values of epoch E-1 (uniform)
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      if (c == ((E - 1) >> 6)) {
+        lam_last = readlane_d(lam_e[c], (E - 1) & 63);
+        cs_last = readlane_d(cs_e[c], (E - 1) & 63);
+      }
+    }
+    const bool absorbing = lam_last > 0;
+    wave_lds_fence();
+    // ============================================================ bin phase (own bins)
+    {
+      double o_g = 0, o_gc = 0, o_h = 0, o_hc = 0, o_N = 0, o_D = 0, llp = 0.0;
+      if (bin_live) {
+        const double lk = my_ep[G_LAM * EPAD + kb], ik = my_ep[G_INV * EPAD + kb];
+        const double ck = my_ep[G_CS * EPAD + kb], Sk = my_ep[G_S * EPAD + kb];
+        const double Xak = my_ep[G_XA * EPAD + kb], PWk = my_ep[G_PW * EPAD + kb];
+        const bool lpos = lk > 0;
+        const double ck1 = ck + lk * da;              // coal_EM.cpp:178-181 at the merged grid
+        const double ck2 = ck1 + lk * (a_b - a_b);    // second copy of `age` in the merged grid
+        const double ck3 = ck2 + lk * db;
+        // ---- EM_shared, coal_EM.cpp:198-210, 263-287
+        const double qd = em::em_exp(-ck1 + ck);
+        // ---- EM_notshared, coal_EM.cpp:330-357, 435-460
+        const double u = em::em_exp(-ck3 + ck2);
+        double Wp = 0.0, Vp = 0.0, pn = 0.0, bn = 0.0;
+        if (lpos) {
+          Wp = Sk * (1.0 - qd);
+          const double X = Xak - (a_b + ik) / ik * qd;
+          Vp = X * ik * Sk;
+          pn = 1.0 - u;
+          bn = (a_b + ik) - (tkn + ik) * u;
+        }
+        double Gk1 = 1.0;
+        if (!absorbing) {  // 1 - S_{E-1}/S_{k+1} >= 0; never taken in a valid run
+          const double csl = my_ep[G_CS * EPAD + (E - 1)];
+          const double csk1 = (kb < E - 1) ? my_ep[G_CS * EPAD + kb + 1] : csl;
+          Gk1 = 1.0 - em::em_exp(-csl + csk1);
+        }
+        const double SigS = PWk + Wp;
+        const double SigN = last_bin ? 1.0 : pn + u * Gk1;
+        const bool okS = (csh > 0) && finite_pos(SigS);
+        const bool okN = (cns > 0) && finite_pos(SigN);
+        const double r = 1.0 / SigS;
+        const double rr = 1.0 / SigN;
+        if (okS) {
+          const double nk = Wp * r;
+          double dk = Vp * r + (-tk * nk);
+          if (dk < 0.0) dk = 0.0;
+          o_g = csh * r;
+          o_gc = csh;
+          o_N = csh * nk;
+          o_D = csh * dk;
+          if (need_ll) llp = csh * em::em_log(SigS);
+        }
+        if (okN) {
+          if (!last_bin) {
+            const double nk = pn * rr;
+            double dk = bn * rr + (-tk * nk + dtk * (1.0 - nk));
+            if (dk < 0.0) dk = 0.0;
+            o_h = cns * (u * rr);
+            o_hc = cns;
+            o_N += cns * nk;
+            o_D += cns * dk;
+            if (need_ll) llp += cns * (-ck2 + em::em_log(SigN));
           } else {  // bin beyond the start of the last epoch, coal_EM.cpp:350-357
             if (!lpos) my_flags |= COLATE_FLAG_NAN;  // reference: assert(coal_rate_e > 0)
             double dk = (a_b + ik) - tk;
             if (dk < 0.0) dk = 0.0;
             o_hc = cns;
-            o_hN = cns;
-            o_hD = cns * dk;
+            o_N += cns;
+            o_D += cns * dk;
             if (need_ll) llp += cns * (-ck2);
           }
         }
-        s_out[O_G * AP + tid] = o_g;
-        s_out[O_GC * AP + tid] = o_gc;
-        s_out[O_GW * AP + tid] = o_gW;
-        s_out[O_GV * AP + tid] = o_gV;
-        s_out[O_H * AP + tid] = o_h;
-        s_out[O_HC * AP + tid] = o_hc;
-        s_out[O_HN * AP + tid] = o_hN;
-        s_out[O_HD * AP + tid] = o_hD;
+      }
+      // sums over the run of equal-epoch bins inside each 16-lane row, left to right
+#define COLATE_SEG_STEP(CTRL, F)                          \
+  o_g = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_g), F, o_g);   \
+  o_gc = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_gc), F, o_gc); \
+  o_h = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_h), F, o_h);   \
+  o_hc = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_hc), F, o_hc); \
+  o_N = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_N), F, o_N);   \
+  o_D = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_D), F, o_D);
+      COLATE_SEG_STEP(ROW_SHR1, f1)
+      COLATE_SEG_STEP(ROW_SHR2, f2)
+      COLATE_SEG_STEP(ROW_SHR4, f4)
+      COLATE_SEG_STEP(ROW_SHR8, f8)
+#undef COLATE_SEG_STEP
+      if (is_tail) {
+        double* dst = s_out + par * kNumBinArrays * AP + tid;
+        dst[O_G * AP] = o_g;
+        dst[O_GC * AP] = o_gc;
+        dst[O_H * AP] = o_h;
+        dst[O_HC * AP] = o_hc;
+        dst[O_N * AP] = o_N;
+        dst[O_D * AP] = o_D;
       }
       if (need_ll) {
-        llp = wave_sum(llp);
-        if ((tid & 63) == 0) s_ll[tid >> 6] = llp;
+        const double tot = readlane_d(wave_prefix_sum(llp), 63);
+        if (lane == 0) s_ll[par * 4 + wave] = tot;
       }
     }
-    __syncthreads();
-    // ---------------------------------------------------------------- P4
-    for (int idx = tid; idx < kNumBinArrays * E; idx += kThreads) {
-      const int e = idx >> 3, arr = idx & 7;
-      const int lo = s_lo[e], hi = s_hi[e];
-      const double* src = s_out + arr * AP;
-      double acc = 0.0;
-      for (int b = lo; b < hi; b++) acc += src[b];
-      s_gs[arr * EP + e] = acc;
-    }
-    __syncthreads();
-    // ---------------------------------------------------------------- P5
-    double N_e = 0, D_e = 0;
-    if (is_ep) {
-      double RS = 0, CS = 0, CN = 0;  // over bins in LATER epochs
-      for (int j = E - 1; j > tid; j--) {
-        RS += s_gs[O_G * EP + j];
-        CS += s_gs[O_GC * EP + j];
-        CN += s_gs[O_HC * EP + j];
+    __syncthreads();  // the one barrier of the iteration (s_out / s_ll are double-buffered)
+    // ============================================================ epoch accumulation (every wave)
+    double N_e[NCH], D_e[NCH];
+    {
+      const double* src = s_out + par * kNumBinArrays * AP;
+      double g[NCH], gc[NCH], h[NCH], hc[NCH], oN[NCH], oD[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        g[c] = gc[c] = h[c] = hc[c] = oN[c] = oD[c] = 0.0;
+        for (int r = row_lo[c]; r <= row_hi[c]; r++) {
+          int slot = r * 16 + 15;
+          if (slot > seg_hi[c] - 1) slot = seg_hi[c] - 1;
+          g[c] += src[O_G * AP + slot];
+          gc[c] += src[O_GC * AP + slot];
+          h[c] += src[O_H * AP + slot];
+          hc[c] += src[O_HC * AP + slot];
+          oN[c] += src[O_N * AP + slot];
+          oD[c] += src[O_D * AP + slot];
+        }
       }
-      double T = 0;  // T_e = sum_{b: k_b < e} c_b u_b/Sig_b * S_e/S_{k_b+1}
-      for (int j = 0; j < tid; j++) T = em::fma_(s_q[j], T, s_gs[O_H * EP + j]);
-      const double gW = s_gs[O_GW * EP + tid], gV = s_gs[O_GV * EP + tid];
-      const double hN = s_gs[O_HN * EP + tid], hD = s_gs[O_HD * EP + tid];
-      N_e = W_e * RS + gW + p_e * T + hN;
-      if (tid < E - 1) {
-        D_e = VW_e * RS + dt_e * (CS - PWn_e * RS) + gV + dt_e * CN + (beta_e - t_e * p_e) * T +
-              dt_e * Gn_e * (q_e * T) + hD;
-      } else {
-        D_e = gV + (beta_e - t_e * p_e) * T + hD;
+      // sums over the bins of LATER epochs: RS = sum c r, CS = sum c (shared), CN = sum c (not shared)
+      double RSn[NCH], CSn[NCH], CNn[NCH];
+      {
+        double cR = 0.0, cC = 0.0, cN = 0.0;
+#pragma unroll
+        for (int c = NCH - 1; c >= 0; c--) {
+          const double sR = wave_suffix_sum(g[c], lane);
+          const double sC = wave_suffix_sum(gc[c], lane);
+          const double sN = wave_suffix_sum(hc[c], lane);
+          RSn[c] = cR + dpp_d<WAVE_SHL1, 0xf, true>(0.0, sR);
+          CSn[c] = cC + dpp_d<WAVE_SHL1, 0xf, true>(0.0, sC);
+          CNn[c] = cN + dpp_d<WAVE_SHL1, 0xf, true>(0.0, sN);
+          cR = cR + readlane_d(sR, 0);
+          cC = cC + readlane_d(sC, 0);
+          cN = cN + readlane_d(sN, 0);
+        }
       }
-      if (N_e != N_e || D_e != D_e) my_flags |= COLATE_FLAG_NAN;  // coal.cpp:3711-3712
-      if (N_e < 0.0 || D_e < 0.0) my_flags |= COLATE_FLAG_NEG;    // coal.cpp:3713-3714
+      // forward recurrence T_{e+1} = q_e T_e + h_e, T_0 = 0
+      // (T_e = sum over not-shared bins b in EARLIER epochs of c_b u_b/Sig_b * S_e/S_{k_b+1})
+      double T[NCH];
+      {
+        double Tc = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+          double a = ep_on[c] ? q_e[c] : 1.0, b = ep_on[c] ? h[c] : 0.0;
+          wave_affine_scan(a, b);
+          const double Tn = em::fma_(a, Tc, b);               // T_{e+1}
+          T[c] = dpp_d<WAVE_SHR1, 0xf, false>(Tc, Tn);        // T_e (lane 0: carry-in)
+          Tc = readlane_d(Tn, 63);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        const int e = c * kWave + lane;
+        N_e[c] = W_e[c] * RSn[c] + oN[c] + p_e[c] * T[c];
+        if (e < E - 1) {
+          double Gn = 1.0;  // G_{e+1}
+          if (!absorbing) Gn = 1.0 - em::em_exp(-cs_last + csn_e[c]);
+          // shared bins of later epochs: sum_b c_b (exp(B_e - Z_b) - t_e num_e(b) + dt_e integ_e(b)); the
+          // reference clamps every bin's term at 0 (coal_EM.cpp:277), here the (non-negative) sums are
+          double integ = CSn[c] - PWn_e[c] * RSn[c];  // sum_b c_b (1 - r_b PW_{e+1})
+          if (integ < 0.0) integ = 0.0;
+          double dsh = VW_e[c] * RSn[c] + dt_e[c] * integ;
+          if (dsh < 0.0) dsh = 0.0;
+          // not-shared bins: later epochs contribute dt_e each, earlier ones their tail mass
+          double dns = dt_e[c] * CNn[c] + ((beta_e[c] - t_e[c] * p_e[c]) * T[c] + dt_e[c] * Gn * (q_e[c] * T[c]));
+          if (dns < 0.0) dns = 0.0;
+          D_e[c] = dsh + oD[c] + dns;
+        } else {
+          double dns = (beta_e[c] - t_e[c] * p_e[c]) * T[c];
+          if (dns < 0.0) dns = 0.0;
+          D_e[c] = oD[c] + dns;
+        }
+        if (ep_on[c]) {
+          if (N_e[c] != N_e[c] || D_e[c] != D_e[c]) my_flags |= COLATE_FLAG_NAN;  // coal.cpp:3711-3712
+          if (N_e[c] < 0.0 || D_e[c] < 0.0) my_flags |= COLATE_FLAG_NEG;          // coal.cpp:3713-3714
+        }
+      }
     }
-    if (need_ll) ll = ((s_ll[0] + s_ll[1]) + s_ll[2]) + s_ll[3];
+    if (need_ll) ll = ((s_ll[par * 4 + 0] + s_ll[par * 4 + 1]) + s_ll[par * 4 + 2]) + s_ll[par * 4 + 3];
     if (MODE == 1) {
-      if (is_ep) {
-        p.out_num[(size_t)rep * E + tid] = N_e;
-        p.out_den[(size_t)rep * E + tid] = D_e;
+      if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+          if (ep_on[c]) {
+            p.out_num[(size_t)rep * E + c * kWave + lane] = N_e[c];
+            p.out_den[(size_t)rep * E + c * kWave + lane] = D_e[c];
+          }
+        }
       }
       break;
     }
-    // M-step candidate, coal.cpp:3777-3804
-    if (is_ep) {
-      const bool copy = (N_e == 0);
-      double cand = lam_e;
-      if (!copy && D_e != 0) {
-        cand = N_e / D_e;
-        if (cand < p.rate_floor) cand = p.rate_floor;
+    // ============================================================ M-step, coal.cpp:3777-3804
+    {
+      double cand[NCH];
+      unsigned long long keep[NCH];  // epochs that do NOT copy their predecessor
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        const bool copy = (N_e[c] == 0);
+        cand[c] = lam_e[c];
+        if (!copy && D_e[c] != 0) {
+          cand[c] = N_e[c] / D_e[c];
+          if (cand[c] < p.rate_floor) cand[c] = p.rate_floor;
+        }
+        keep[c] = __ballot(ep_on[c] && !copy);
       }
-      s_cand[tid] = cand;
-      s_copy[tid] = copy ? 1 : 0;
-    }
-    __syncthreads();
-    // ---------------------------------------------------------------- P6
-    if (is_ep) {
-      int j = tid;
-      while (j >= 0 && s_copy[j]) j--;  // coal.cpp:3779-3786 (already-updated previous rate)
-      lam_e = (j >= 0) ? s_cand[j] : 0.0;
+      // num == 0: take the (already updated) rate of the previous epoch, 0 if there is none
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        const unsigned long long below = keep[c] & ((1ull << lane) - 1ull);
+        const int src = below ? 63 - __builtin_clzll(below) : 0;
+        const double from_chunk = __shfl(cand[c], src, 64);
+        double from_lower = 0.0;  // nearest keeper in an earlier chunk (uniform)
+        bool have_lower = false;
+#pragma unroll
+        for (int cc = NCH - 1; cc >= 0; cc--) {
+          if (cc < c && !have_lower && keep[cc]) {
+            from_lower = readlane_d(cand[cc], 63 - __builtin_clzll(keep[cc]));
+            have_lower = true;
+          }
+        }
+        const bool self = (keep[c] >> lane) & 1ull;
+        lam_e[c] = ep_on[c] ? (self ? cand[c] : (below ? from_chunk : from_lower)) : 0.0;
+      }
     }
     // stop rule, coal.cpp:3822 (evaluated after the update); uniform across the workgroup
     const bool stop = (ll / prev_ll > thr) & (iter > p.min_iter);
@@ -356,9 +544,14 @@ __global__ __launch_bounds__(kThreads) void em_kernel(ColateEmArgs p) {
   }
 
   // ------------------------------------------------------------------ epilogue
-  if (MODE == 0 && is_ep) {
-    if (lam_e != lam_e) my_flags |= COLATE_FLAG_NAN;
-    p.out_rates[(size_t)rep * E + tid] = lam_e;
+  if (MODE == 0 && wave == 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      if (ep_on[c]) {
+        if (lam_e[c] != lam_e[c]) my_flags |= COLATE_FLAG_NAN;
+        p.out_rates[(size_t)rep * E + c * kWave + lane] = lam_e[c];
+      }
+    }
   }
   if (my_flags) atomicOr(&s_misc[2], my_flags);
   __syncthreads();
@@ -373,22 +566,42 @@ __global__ __launch_bounds__(kThreads) void em_kernel(ColateEmArgs p) {
   }
 }
 
+template <int MODE, int NCH>
+hipError_t launch_one(const ColateEmArgs& args, hipStream_t stream, size_t lds, int threads) {
+  auto kern = em_kernel<MODE, NCH>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(args.B), dim3(threads), lds, stream, args);
+  return hipGetLastError();
+}
+
 }  // namespace
 
+static int em_threads(int A) { return (A + 63) & ~63; }
+static int em_chunks(int E) { return E <= 64 ? 1 : (E <= 128 ? 2 : 4); }
+
 size_t colate_em_lds_bytes(int E, int A) {
-  const size_t EP = (size_t)E + 1;
-  const size_t AP = ((size_t)A + 63) & ~(size_t)63;
-  size_t doubles = 13 * EP + kNumBinArrays * EP + kNumBinArrays * AP + 4;
-  size_t ints = AP + 3 * EP + 4;
+  const size_t EPAD = (size_t)em_chunks(E) * kWave;
+  const size_t AP = (size_t)em_threads(A);
+  const size_t nwaves = AP / kWave;
+  const size_t doubles = (EPAD + 1) + nwaves * kNumGather * EPAD + 2 * kNumBinArrays * AP + 8;
+  const size_t ints = (AP + 1) + 4;
   return doubles * sizeof(double) + ints * sizeof(int);
 }
 
 hipError_t colate_em_launch(const ColateEmArgs& args, hipStream_t stream) {
   const size_t lds = colate_em_lds_bytes(args.E, args.A);
-  dim3 grid(args.B), block(kThreads);
-  if (args.mode == 1)
-    hipLaunchKernelGGL(em_kernel<1>, grid, block, lds, stream, args);
-  else
-    hipLaunchKernelGGL(em_kernel<0>, grid, block, lds, stream, args);
-  return hipGetLastError();
+  const int threads = em_threads(args.A);
+  const int nch = em_chunks(args.E);
+  if (args.mode == 1) {
+    if (nch == 1) return launch_one<1, 1>(args, stream, lds, threads);
+    if (nch == 2) return launch_one<1, 2>(args, stream, lds, threads);
+    return launch_one<1, 4>(args, stream, lds, threads);
+  }
+  if (nch == 1) return launch_one<0, 1>(args, stream, lds, threads);
+  if (nch == 2) return launch_one<0, 2>(args, stream, lds, threads);
+  return launch_one<0, 4>(args, stream, lds, threads);
 }
