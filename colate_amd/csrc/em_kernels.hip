@@ -19,7 +19,9 @@
 //    wave-local DPP scans and no barrier separates them from the bin phase;
 //  * age bins are one per thread; their per-epoch sums are reduced in registers
 //    (row-segmented DPP) and handed to the epoch lanes through a double-buffered
-//    LDS tile: ONE workgroup barrier per EM iteration.
+//    LDS tile: ONE workgroup barrier per EM iteration;
+//  * sums the model makes telescope are not summed: sum_{j<e} exp(A_j) = 1 - exp(-cs_e),
+//    and the not-shared normaliser is exp(-cs(age)) whenever the last epoch absorbs.
 //
 // The reference evaluates exp(log-term - Z) for every (age bin, epoch) pair:
 // O(A*E) transcendentals per iteration.  Here every such term is factored into
@@ -38,7 +40,7 @@
 namespace {
 
 constexpr int kWave = 64;
-enum { O_G = 0, O_GC, O_H, O_HC, O_N, O_D, kNumBinArrays };            // per-bin values -> epochs
+enum { O_G = 0, O_H, O_N, O_D, kNumBinArrays };                        // per-bin values -> epochs
 enum { G_LAM = 0, G_INV, G_CS, G_S, G_XA, G_PW, kNumGather };           // per-epoch values -> bins
 
 // ----------------------------------------------------------------- lane plumbing
@@ -101,6 +103,30 @@ __device__ __forceinline__ void wave_affine_scan(double& a, double& b) {
 #undef COLATE_AFF_STEP
 }
 
+#ifdef COLATE_EM_STAMPS
+// diagnostic build only (tools/em_phase_probe.hip): cycle stamps around the phases of an iteration
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define COLATE_STAMP(i)                     \
+  {                                         \
+    const unsigned long long now_ = stamp(); \
+    st_acc[i] += now_ - st_prev;            \
+    st_prev = now_;                         \
+  }
+#else
+#define COLATE_STAMP(i)
+#endif
+
+// Marks a rarely-taken branch body: a volatile asm cannot be executed speculatively, so the compiler
+// keeps the branch instead of if-converting it (it otherwise evaluates whole exp()/log() calls of
+// cold paths unconditionally and selects the result).
+#define COLATE_COLD() asm volatile("; cold path")
+
 __device__ __forceinline__ bool finite_pos(double x) { return x > 0.0 && x < __builtin_inf(); }
 
 // wave-local LDS hand-off: earlier ds_writes of this wave are visible to its later ds_reads
@@ -118,17 +144,21 @@ __global__ __launch_bounds__(COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
   const int E = p.E, A = p.A;
   constexpr int EPAD = NCH * kWave;
   const int AP = blockDim.x;  // A rounded up to a multiple of 64
+  const int APZ = AP + 16;    // stride of the per-bin tiles; entries [AP, APZ) stay zero
   const int nwaves = AP >> 6;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rep = blockIdx.x;
 
   // ---- LDS carve-up ----
-  double* s_t = lds;                                            // [EPAD + 1] epoch starts
-  double* s_ep = s_t + EPAD + 1;                                // [nwaves][kNumGather][EPAD] per-wave epoch values
-  double* s_out = s_ep + nwaves * kNumGather * EPAD;            // [2][kNumBinArrays][AP] per-bin tails
-  double* s_ll = s_out + 2 * kNumBinArrays * AP;                // [2][4] per-wave log-likelihood partials
-  int* s_kb = reinterpret_cast<int*>(s_ll + 8);                 // [AP + 1] epoch of each bin
-  int* s_misc = s_kb + AP + 1;                                  // [4] nzlo, nzhi, flags
+  double* s_t = lds;                                     // [EPAD + 1] epoch starts
+  double* s_ep = s_t + EPAD + 1;                         // [nwaves][kNumGather][EPAD] per-wave epoch values
+  double* s_out = s_ep + nwaves * kNumGather * EPAD;     // [2][kNumBinArrays][APZ] per-bin tails
+  double* s_cfail = s_out + 2 * kNumBinArrays * APZ;     // [2][2][APZ] counts of bins whose normaliser failed
+  double* s_cnt = s_cfail + 4 * APZ;                     // [2][APZ] counts (prologue only)
+  double* s_ll = s_cnt + 2 * APZ;                        // [2][4] per-wave log-likelihood partials
+  int* s_kb = reinterpret_cast<int*>(s_ll + 8);          // [AP + 1] epoch of each bin
+  int* s_fail = s_kb + AP + 1;                           // [2][4] per-wave "a bin failed" flags
+  int* s_misc = s_fail + 8;                              // [4] nzlo, nzhi, flags
   double* my_ep = s_ep + wave * kNumGather * EPAD;
 
   // ------------------------------------------------------------------ prologue
@@ -139,8 +169,11 @@ __global__ __launch_bounds__(COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
     s_misc[1] = 0;
     s_misc[2] = 0;
   }
-  if (tid < 8) s_ll[tid] = 0.0;
-  for (int i = tid; i < 2 * kNumBinArrays * AP; i += AP) s_out[i] = 0.0;
+  if (tid < 8) {
+    s_ll[tid] = 0.0;
+    s_fail[tid] = 0;
+  }
+  for (int i = tid; i < 2 * kNumBinArrays * APZ + 6 * APZ; i += AP) s_out[i] = 0.0;  // s_out, s_cfail, s_cnt
   __syncthreads();
 
   // epoch-role statics (identical in every wave)
@@ -191,6 +224,8 @@ __global__ __launch_bounds__(COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
     }
     da = a_b - tk;
     db = tkn - a_b;
+    s_cnt[tid] = csh;
+    s_cnt[APZ + tid] = cns;
     if (csh > 0 || cns > 0) {
       atomicMin(&s_misc[0], tid);
       atomicMax(&s_misc[1], tid + 1);
@@ -212,75 +247,89 @@ __global__ __launch_bounds__(COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
     if (r >= 8 && s_kb[tid - 8] == kb) f8 = 1.0;
   }
   const bool is_tail = is_bin && ((lane & 15) == 15 || s_kb[tid + 1] != kb);
-  // epoch-role: rows of the bin tile that hold tails of this epoch, clipped to the bins with data
-  int row_lo[NCH], row_hi[NCH], seg_hi[NCH];
+  // epoch-role: where the tails of this epoch sit in the bin tile (clipped to the bins with data),
+  // and the counts of the bins in LATER epochs (CS = shared, CN = not shared)
+  int slot0[NCH], slot1[NCH], slot2[NCH], row_x[NCH], row_hi[NCH], seg_hi[NCH];
+  double CS0[NCH], CN0[NCH];
   {
     const int nzlo = s_misc[0], nzhi = s_misc[1];
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       const int e = c * kWave + lane;
       int lo = A, hi = 0;
+      double cs_later = 0.0, cn_later = 0.0;
       if (ep_on[c]) {
         for (int b = 0; b < A; b++) {
-          if (s_kb[b] == e) {
+          const int k = s_kb[b];
+          if (k == e) {
             if (b < lo) lo = b;
             hi = b + 1;
           }
+          if (k > e) {
+            cs_later += s_cnt[b];
+            cn_later += s_cnt[APZ + b];
+          }
         }
       }
+      CS0[c] = cs_later;
+      CN0[c] = cn_later;
       seg_hi[c] = hi;
       const int clo = lo > nzlo ? lo : nzlo, chi = hi < nzhi ? hi : nzhi;
+      slot0[c] = slot1[c] = slot2[c] = AP;  // a zero entry
+      row_x[c] = 1;
+      row_hi[c] = 0;
       if (clo < chi) {
-        row_lo[c] = clo >> 4;
-        row_hi[c] = (chi - 1) >> 4;
-      } else {
-        row_lo[c] = 1;
-        row_hi[c] = 0;
+        const int r0 = clo >> 4, r1 = (chi - 1) >> 4;
+        slot0[c] = (r0 * 16 + 15 < hi - 1) ? r0 * 16 + 15 : hi - 1;
+        if (r1 > r0) slot1[c] = ((r0 + 1) * 16 + 15 < hi - 1) ? (r0 + 1) * 16 + 15 : hi - 1;
+        if (r1 > r0 + 1) slot2[c] = ((r0 + 2) * 16 + 15 < hi - 1) ? (r0 + 2) * 16 + 15 : hi - 1;
+        row_x[c] = r0 + 3;  // rows beyond the first three (rare: an epoch spanning > 48 bins with data)
+        row_hi[c] = r1;
       }
     }
   }
   int my_flags = 0;
+  bool wrote_fail0 = false, wrote_fail1 = false;  // this lane published a failed count into buffer 0 / 1
 
   const double thr = 1.0 - p.rel_tol;
   double ll = -__builtin_inf(), prev_ll = -__builtin_inf();  // coal.cpp:3685
   int iter = 0;
   const int max_iter = (MODE == 1) ? 1 : p.max_iter;
 
+#ifdef COLATE_EM_STAMPS
+  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_prev = stamp();
+#endif
   for (iter = 0; iter < max_iter; iter++) {
+    COLATE_STAMP(7)
     const bool need_ll = (MODE == 1) || (iter >= p.min_iter) || (iter == max_iter - 1);
     const int par = iter & 1;
     // ============================================================ epoch phase (every wave)
     double q_e[NCH], p_e[NCH], beta_e[NCH], W_e[NCH], VW_e[NCH], PWn_e[NCH], cs_e[NCH], csn_e[NCH];
     {
-      double x[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; c++) x[c] = lam_e[c] * dt_e[c];
-      // cs_e = ((x_0 + x_1) + ...) + x_{e-1}, in this order (coal_EM.cpp:100-103)
-      double* cs = cs_e;
-      double run = 0.0;  // uniform running sum; lane j of chunk c snapshots it before x_j is added
+      // cs_e = sum_{j<e} lambda_j dt_j (coal_EM.cpp:100-103), as a wave scan
+      double carry = 0.0;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
-        cs[c] = 0.0;
-        const int jmax = (E - c * kWave) < kWave ? (E - c * kWave) : kWave;
-        for (int j = 0; j < jmax; j++) {
-          if (lane == j) cs[c] = run;
-          run = run + readlane_d(x[c], j);
-        }
+        const double x = lam_e[c] * dt_e[c];
+        const double incl = wave_prefix_sum(x);
+        cs_e[c] = carry + dpp_d<WAVE_SHR1, 0xf, true>(0.0, incl);
+        csn_e[c] = cs_e[c] + x;
+        carry = carry + readlane_d(incl, 63);
       }
-      double pw_carry = 0.0;
+      COLATE_STAMP(8)
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         const int e = c * kWave + lane;
-        const double csn = cs[c] + x[c];
-        csn_e[c] = csn;
         const double inv = 1.0 / lam_e[c];
-        const double S = em::em_exp(-cs[c]);
+        double omS;  // 1 - S_e = sum_{j<e} exp(A_ep[j])   (the shared normaliser's epoch part)
+        const double S = em::em_exp_om(-cs_e[c], &omS);
         const bool valid = vstat[c] && (lam_e[c] > 0);
         q_e[c] = 0.0;
         p_e[c] = 0.0;
         beta_e[c] = 0.0;
         if (e < E - 1) {
-          q_e[c] = em::em_exp(-csn + cs[c]);  // exp(-cumsum[i+1] + cumsum[i]), coal_EM.cpp:120
+          q_e[c] = em::em_exp(-csn_e[c] + cs_e[c]);  // exp(-cumsum[i+1] + cumsum[i]), coal_EM.cpp:120
           if (valid) {
             p_e[c] = 1.0 - q_e[c];                                  // exp(A_ep + cs), coal_EM.cpp:119
             beta_e[c] = (t_e[c] + inv) - (tn_e[c] + inv) * q_e[c];  // exp(B_ep + cs), coal_EM.cpp:120
@@ -291,17 +340,15 @@ __global__ __launch_bounds__(COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
         }
         W_e[c] = ep_on[c] ? S * p_e[c] : 0.0;
         VW_e[c] = ep_on[c] ? S * beta_e[c] - t_e[c] * W_e[c] : 0.0;
-        const double incl = wave_prefix_sum(W_e[c]);
-        const double pw = pw_carry + dpp_d<WAVE_SHR1, 0xf, true>(0.0, incl);  // PW_e = sum_{j<e} W_j
-        PWn_e[c] = pw + W_e[c];
-        pw_carry = pw_carry + readlane_d(incl, 63);
+        PWn_e[c] = omS + W_e[c];  // sum_{j<=e} exp(A_ep[j])
+        COLATE_STAMP(9)
         if (ep_on[c]) {
           my_ep[G_LAM * EPAD + e] = lam_e[c];
           my_ep[G_INV * EPAD + e] = inv;
-          my_ep[G_CS * EPAD + e] = cs[c];
+          my_ep[G_CS * EPAD + e] = cs_e[c];
           my_ep[G_S * EPAD + e] = S;
           my_ep[G_XA * EPAD + e] = (t_e[c] + inv) / inv;  // coal_EM.cpp:204
-          my_ep[G_PW * EPAD + e] = pw;
+          my_ep[G_PW * EPAD + e] = omS;
         }
       }
     }
@@ -319,78 +366,99 @@ __global__ __launch_bounds__(COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
     }
     const bool absorbing = lam_last > 0;
     wave_lds_fence();
+    COLATE_STAMP(0)
     // ============================================================ bin phase (own bins)
     {
-      double o_g = 0, o_gc = 0, o_h = 0, o_hc = 0, o_N = 0, o_D = 0, llp = 0.0;
+      double o_g = 0, o_h = 0, o_N = 0, o_D = 0, llp = 0.0;
+      bool failS = false, failN = false;
       if (bin_live) {
         const double lk = my_ep[G_LAM * EPAD + kb], ik = my_ep[G_INV * EPAD + kb];
         const double ck = my_ep[G_CS * EPAD + kb], Sk = my_ep[G_S * EPAD + kb];
         const double Xak = my_ep[G_XA * EPAD + kb], PWk = my_ep[G_PW * EPAD + kb];
         const bool lpos = lk > 0;
-        const double ck1 = ck + lk * da;              // coal_EM.cpp:178-181 at the merged grid
-        const double ck2 = ck1 + lk * (a_b - a_b);    // second copy of `age` in the merged grid
+        const double ck1 = ck + lk * da;            // coal_EM.cpp:178-181 at the merged grid
+        const double ck2 = ck1 + lk * (a_b - a_b);  // second copy of `age` in the merged grid
         const double ck3 = ck2 + lk * db;
-        // ---- EM_shared, coal_EM.cpp:198-210, 263-287
-        const double qd = em::em_exp(-ck1 + ck);
-        // ---- EM_notshared, coal_EM.cpp:330-357, 435-460
-        const double u = em::em_exp(-ck3 + ck2);
-        double Wp = 0.0, Vp = 0.0, pn = 0.0, bn = 0.0;
-        if (lpos) {
-          Wp = Sk * (1.0 - qd);
-          const double X = Xak - (a_b + ik) / ik * qd;
-          Vp = X * ik * Sk;
-          pn = 1.0 - u;
-          bn = (a_b + ik) - (tkn + ik) * u;
-        }
-        double Gk1 = 1.0;
-        if (!absorbing) {  // 1 - S_{E-1}/S_{k+1} >= 0; never taken in a valid run
-          const double csl = my_ep[G_CS * EPAD + (E - 1)];
-          const double csk1 = (kb < E - 1) ? my_ep[G_CS * EPAD + kb + 1] : csl;
-          Gk1 = 1.0 - em::em_exp(-csl + csk1);
-        }
+        const double qd = em::em_exp(-ck1 + ck);  // EM_shared, coal_EM.cpp:198-210, 263-287
+        const double u = em::em_exp(-ck3 + ck2);  // EM_notshared, coal_EM.cpp:330-357, 435-460
+        const double Y = (a_b + ik) / ik;
+        const double Wp = lpos ? Sk * (1.0 - qd) : 0.0;
+        const double X = Xak - Y * qd;
+        const double Vp = lpos ? X * ik * Sk : 0.0;
+        const double pn = lpos ? 1.0 - u : 0.0;
+        const double bn = lpos ? (a_b + ik) - (tkn + ik) * u : 0.0;
+        // ---- shared
         const double SigS = PWk + Wp;
-        const double SigN = last_bin ? 1.0 : pn + u * Gk1;
-        const bool okS = (csh > 0) && finite_pos(SigS);
-        const bool okN = (cns > 0) && finite_pos(SigN);
-        const double r = 1.0 / SigS;
-        const double rr = 1.0 / SigN;
-        if (okS) {
+        const bool okS = finite_pos(SigS);
+        failS = (csh > 0) && !okS;
+        if (csh > 0 && okS) {
+          const double r = em::em_rcp(SigS);
           const double nk = Wp * r;
           double dk = Vp * r + (-tk * nk);
           if (dk < 0.0) dk = 0.0;
           o_g = csh * r;
-          o_gc = csh;
           o_N = csh * nk;
           o_D = csh * dk;
-          if (need_ll) llp = csh * em::em_log(SigS);
+          if (need_ll) {
+            COLATE_COLD();
+            llp = csh * em::em_log(SigS);
+          }
         }
-        if (okN) {
-          if (!last_bin) {
-            const double nk = pn * rr;
-            double dk = bn * rr + (-tk * nk + dtk * (1.0 - nk));
-            if (dk < 0.0) dk = 0.0;
-            o_h = cns * (u * rr);
-            o_hc = cns;
-            o_N += cns * nk;
-            o_D += cns * dk;
-            if (need_ll) llp += cns * (-ck2 + em::em_log(SigN));
-          } else {  // bin beyond the start of the last epoch, coal_EM.cpp:350-357
+        // ---- not shared
+        if (cns > 0) {
+          if (last_bin) {  // bin beyond the start of the last epoch, coal_EM.cpp:350-357
             if (!lpos) my_flags |= COLATE_FLAG_NAN;  // reference: assert(coal_rate_e > 0)
             double dk = (a_b + ik) - tk;
             if (dk < 0.0) dk = 0.0;
-            o_hc = cns;
             o_N += cns;
             o_D += cns * dk;
-            if (need_ll) llp += cns * (-ck2);
+            llp += cns * (-ck2);
+          } else if (absorbing) {  // normaliser = exp(-cs(age)) * ((1 - u) + u) = exp(-cs(age))
+            double dk = bn + (-tk * pn + dtk * (1.0 - pn));
+            if (dk < 0.0) dk = 0.0;
+            o_h = cns * u;
+            o_N += cns * pn;
+            o_D += cns * dk;
+            llp += cns * (-ck2);
+          } else {  // last rate is 0: the mass beyond t_{k+1} is 1 - S_{E-1}/S_{k+1}
+            COLATE_COLD();
+            const double Gk1 = 1.0 - em::em_exp(-cs_last + my_ep[G_CS * EPAD + kb + 1]);
+            const double SigN = pn + u * Gk1;
+            if (finite_pos(SigN)) {
+              const double rr = 1.0 / SigN;
+              const double nk = pn * rr;
+              double dk = bn * rr + (-tk * nk + dtk * (1.0 - nk));
+              if (dk < 0.0) dk = 0.0;
+              o_h = cns * (u * rr);
+              o_N += cns * nk;
+              o_D += cns * dk;
+              if (need_ll) llp += cns * (-ck2 + em::em_log(SigN));
+            } else {
+              failN = true;
+            }
           }
         }
       }
+      COLATE_STAMP(1)
+      // bins whose normaliser failed (coal_EM.cpp:288-292, 461-465) drop out of the static counts
+      {
+        const bool any_fail = __any(failS || failN);
+        const bool wrote = par ? wrote_fail1 : wrote_fail0;
+        if (failS || failN || wrote) {  // publish, or clear what this lane published two iterations ago
+          COLATE_COLD();
+          s_cfail[(par * 2 + 0) * APZ + tid] = failS ? csh : 0.0;
+          s_cfail[(par * 2 + 1) * APZ + tid] = failN ? cns : 0.0;
+        }
+        if (par)
+          wrote_fail1 = failS || failN;
+        else
+          wrote_fail0 = failS || failN;
+        if (lane == 0) s_fail[par * 4 + wave] = any_fail ? 1 : 0;
+      }
       // sums over the run of equal-epoch bins inside each 16-lane row, left to right
-#define COLATE_SEG_STEP(CTRL, F)                          \
+#define COLATE_SEG_STEP(CTRL, F)                              \
   o_g = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_g), F, o_g);   \
-  o_gc = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_gc), F, o_gc); \
   o_h = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_h), F, o_h);   \
-  o_hc = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_hc), F, o_hc); \
   o_N = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_N), F, o_N);   \
   o_D = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_D), F, o_D);
       COLATE_SEG_STEP(ROW_SHR1, f1)
@@ -399,56 +467,59 @@ __global__ __launch_bounds__(COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
       COLATE_SEG_STEP(ROW_SHR8, f8)
 #undef COLATE_SEG_STEP
       if (is_tail) {
-        double* dst = s_out + par * kNumBinArrays * AP + tid;
-        dst[O_G * AP] = o_g;
-        dst[O_GC * AP] = o_gc;
-        dst[O_H * AP] = o_h;
-        dst[O_HC * AP] = o_hc;
-        dst[O_N * AP] = o_N;
-        dst[O_D * AP] = o_D;
+        double* dst = s_out + par * kNumBinArrays * APZ + tid;
+        dst[O_G * APZ] = o_g;
+        dst[O_H * APZ] = o_h;
+        dst[O_N * APZ] = o_N;
+        dst[O_D * APZ] = o_D;
       }
       if (need_ll) {
+        COLATE_COLD();
         const double tot = readlane_d(wave_prefix_sum(llp), 63);
         if (lane == 0) s_ll[par * 4 + wave] = tot;
       }
     }
-    __syncthreads();  // the one barrier of the iteration (s_out / s_ll are double-buffered)
+    COLATE_STAMP(2)
+    __syncthreads();  // the one barrier of the iteration (the LDS tiles are double-buffered)
+    COLATE_STAMP(3)
     // ============================================================ epoch accumulation (every wave)
     double N_e[NCH], D_e[NCH];
     {
-      const double* src = s_out + par * kNumBinArrays * AP;
-      double g[NCH], gc[NCH], h[NCH], hc[NCH], oN[NCH], oD[NCH];
+      const double* src = s_out + par * kNumBinArrays * APZ;
+      double g[NCH], h[NCH], oN[NCH], oD[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
-        g[c] = gc[c] = h[c] = hc[c] = oN[c] = oD[c] = 0.0;
-        for (int r = row_lo[c]; r <= row_hi[c]; r++) {
+        const double g0 = src[O_G * APZ + slot0[c]], g1 = src[O_G * APZ + slot1[c]], g2 = src[O_G * APZ + slot2[c]];
+        const double h0 = src[O_H * APZ + slot0[c]], h1 = src[O_H * APZ + slot1[c]], h2 = src[O_H * APZ + slot2[c]];
+        const double n0 = src[O_N * APZ + slot0[c]], n1 = src[O_N * APZ + slot1[c]], n2 = src[O_N * APZ + slot2[c]];
+        const double d0 = src[O_D * APZ + slot0[c]], d1 = src[O_D * APZ + slot1[c]], d2 = src[O_D * APZ + slot2[c]];
+        g[c] = (g0 + g1) + g2;
+        h[c] = (h0 + h1) + h2;
+        oN[c] = (n0 + n1) + n2;
+        oD[c] = (d0 + d1) + d2;
+        for (int r = row_x[c]; r <= row_hi[c]; r++) {
+          COLATE_COLD();
           int slot = r * 16 + 15;
           if (slot > seg_hi[c] - 1) slot = seg_hi[c] - 1;
-          g[c] += src[O_G * AP + slot];
-          gc[c] += src[O_GC * AP + slot];
-          h[c] += src[O_H * AP + slot];
-          hc[c] += src[O_HC * AP + slot];
-          oN[c] += src[O_N * AP + slot];
-          oD[c] += src[O_D * AP + slot];
+          g[c] += src[O_G * APZ + slot];
+          h[c] += src[O_H * APZ + slot];
+          oN[c] += src[O_N * APZ + slot];
+          oD[c] += src[O_D * APZ + slot];
         }
       }
-      // sums over the bins of LATER epochs: RS = sum c r, CS = sum c (shared), CN = sum c (not shared)
-      double RSn[NCH], CSn[NCH], CNn[NCH];
+      COLATE_STAMP(10)
+      // RS = sum c r over the shared bins of LATER epochs
+      double RSn[NCH];
       {
-        double cR = 0.0, cC = 0.0, cN = 0.0;
+        double cR = 0.0;
 #pragma unroll
         for (int c = NCH - 1; c >= 0; c--) {
           const double sR = wave_suffix_sum(g[c], lane);
-          const double sC = wave_suffix_sum(gc[c], lane);
-          const double sN = wave_suffix_sum(hc[c], lane);
           RSn[c] = cR + dpp_d<WAVE_SHL1, 0xf, true>(0.0, sR);
-          CSn[c] = cC + dpp_d<WAVE_SHL1, 0xf, true>(0.0, sC);
-          CNn[c] = cN + dpp_d<WAVE_SHL1, 0xf, true>(0.0, sN);
           cR = cR + readlane_d(sR, 0);
-          cC = cC + readlane_d(sC, 0);
-          cN = cN + readlane_d(sN, 0);
         }
       }
+      COLATE_STAMP(11)
       // forward recurrence T_{e+1} = q_e T_e + h_e, T_0 = 0
       // (T_e = sum over not-shared bins b in EARLIER epochs of c_b u_b/Sig_b * S_e/S_{k_b+1})
       double T[NCH];
@@ -458,9 +529,32 @@ __global__ __launch_bounds__(COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
         for (int c = 0; c < NCH; c++) {
           double a = ep_on[c] ? q_e[c] : 1.0, b = ep_on[c] ? h[c] : 0.0;
           wave_affine_scan(a, b);
-          const double Tn = em::fma_(a, Tc, b);               // T_{e+1}
-          T[c] = dpp_d<WAVE_SHR1, 0xf, false>(Tc, Tn);        // T_e (lane 0: carry-in)
+          const double Tn = em::fma_(a, Tc, b);         // T_{e+1}
+          T[c] = dpp_d<WAVE_SHR1, 0xf, false>(Tc, Tn);  // T_e (lane 0: carry-in)
           Tc = readlane_d(Tn, 63);
+        }
+      }
+      COLATE_STAMP(12)
+      // counts of the bins in LATER epochs, minus those whose normaliser failed this iteration
+      double CSn[NCH], CNn[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        CSn[c] = CS0[c];
+        CNn[c] = CN0[c];
+      }
+      if (s_fail[par * 4 + 0] | s_fail[par * 4 + 1] | s_fail[par * 4 + 2] | s_fail[par * 4 + 3]) {
+        COLATE_COLD();
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+          double fs = 0.0, fn = 0.0;
+          for (int b = seg_hi[c]; ep_on[c] && b < A; b++) {
+            if (s_kb[b] > c * kWave + lane) {
+              fs += s_cfail[(par * 2 + 0) * APZ + b];
+              fn += s_cfail[(par * 2 + 1) * APZ + b];
+            }
+          }
+          CSn[c] -= fs;
+          CNn[c] -= fn;
         }
       }
 #pragma unroll
@@ -469,7 +563,10 @@ __global__ __launch_bounds__(COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
         N_e[c] = W_e[c] * RSn[c] + oN[c] + p_e[c] * T[c];
         if (e < E - 1) {
           double Gn = 1.0;  // G_{e+1}
-          if (!absorbing) Gn = 1.0 - em::em_exp(-cs_last + csn_e[c]);
+          if (!absorbing) {
+            COLATE_COLD();
+            Gn = 1.0 - em::em_exp(-cs_last + csn_e[c]);
+          }
           // shared bins of later epochs: sum_b c_b (exp(B_e - Z_b) - t_e num_e(b) + dt_e integ_e(b)); the
           // reference clamps every bin's term at 0 (coal_EM.cpp:277), here the (non-negative) sums are
           double integ = CSn[c] - PWn_e[c] * RSn[c];  // sum_b c_b (1 - r_b PW_{e+1})
@@ -485,13 +582,17 @@ __global__ __launch_bounds__(COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
           if (dns < 0.0) dns = 0.0;
           D_e[c] = oD[c] + dns;
         }
-        if (ep_on[c]) {
+        if (MODE == 1 && ep_on[c]) {  // (EM mode: a NaN sticks to the rate and is flagged at the end)
           if (N_e[c] != N_e[c] || D_e[c] != D_e[c]) my_flags |= COLATE_FLAG_NAN;  // coal.cpp:3711-3712
           if (N_e[c] < 0.0 || D_e[c] < 0.0) my_flags |= COLATE_FLAG_NEG;          // coal.cpp:3713-3714
         }
       }
     }
-    if (need_ll) ll = ((s_ll[par * 4 + 0] + s_ll[par * 4 + 1]) + s_ll[par * 4 + 2]) + s_ll[par * 4 + 3];
+    COLATE_STAMP(4)
+    if (need_ll) {
+      COLATE_COLD();
+      ll = ((s_ll[par * 4 + 0] + s_ll[par * 4 + 1]) + s_ll[par * 4 + 2]) + s_ll[par * 4 + 3];
+    }
     if (MODE == 1) {
       if (wave == 0) {
 #pragma unroll
@@ -508,6 +609,8 @@ __global__ __launch_bounds__(COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
     {
       double cand[NCH];
       unsigned long long keep[NCH];  // epochs that do NOT copy their predecessor
+      bool simple = true;            // the copying epochs form a prefix 0..m-1: they all become 0
+      bool lower_keep = false;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         const bool copy = (N_e[c] == 0);
@@ -517,32 +620,52 @@ __global__ __launch_bounds__(COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
           if (cand[c] < p.rate_floor) cand[c] = p.rate_floor;
         }
         keep[c] = __ballot(ep_on[c] && !copy);
+        const unsigned long long cp = __ballot(ep_on[c] && copy);
+        if (cp && (lower_keep || (cp & (cp + 1ull)))) simple = false;
+        if (keep[c]) lower_keep = true;
       }
-      // num == 0: take the (already updated) rate of the previous epoch, 0 if there is none
+      if (simple) {
 #pragma unroll
-      for (int c = 0; c < NCH; c++) {
-        const unsigned long long below = keep[c] & ((1ull << lane) - 1ull);
-        const int src = below ? 63 - __builtin_clzll(below) : 0;
-        const double from_chunk = __shfl(cand[c], src, 64);
-        double from_lower = 0.0;  // nearest keeper in an earlier chunk (uniform)
-        bool have_lower = false;
+        for (int c = 0; c < NCH; c++) lam_e[c] = ((keep[c] >> lane) & 1ull) ? cand[c] : 0.0;
+      } else {
+        COLATE_COLD();
+        // num == 0: take the (already updated) rate of the previous epoch, 0 if there is none
 #pragma unroll
-        for (int cc = NCH - 1; cc >= 0; cc--) {
-          if (cc < c && !have_lower && keep[cc]) {
-            from_lower = readlane_d(cand[cc], 63 - __builtin_clzll(keep[cc]));
-            have_lower = true;
+        for (int c = 0; c < NCH; c++) {
+          const unsigned long long below = keep[c] & ((1ull << lane) - 1ull);
+          const int src = below ? 63 - __builtin_clzll(below) : 0;
+          const double from_chunk = __shfl(cand[c], src, 64);
+          double from_lower = 0.0;  // nearest keeper in an earlier chunk (uniform)
+          bool have_lower = false;
+#pragma unroll
+          for (int cc = NCH - 1; cc >= 0; cc--) {
+            if (cc < c && !have_lower && keep[cc]) {
+              from_lower = readlane_d(cand[cc], 63 - __builtin_clzll(keep[cc]));
+              have_lower = true;
+            }
           }
+          const bool self = (keep[c] >> lane) & 1ull;
+          lam_e[c] = ep_on[c] ? (self ? cand[c] : (below ? from_chunk : from_lower)) : 0.0;
         }
-        const bool self = (keep[c] >> lane) & 1ull;
-        lam_e[c] = ep_on[c] ? (self ? cand[c] : (below ? from_chunk : from_lower)) : 0.0;
       }
     }
+    COLATE_STAMP(5)
     // stop rule, coal.cpp:3822 (evaluated after the update); uniform across the workgroup
-    const bool stop = (ll / prev_ll > thr) & (iter > p.min_iter);
+    bool stop = false;
+    if (iter > p.min_iter) {
+      COLATE_COLD();
+      stop = (ll / prev_ll > thr);
+    }
     prev_ll = ll;
     if (stop) break;
   }
 
+#ifdef COLATE_EM_STAMPS
+  if (p.out_num && lane == 0 && MODE == 0) {  // diagnostic build: per-wave phase cycles in place of out_num
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out_num) + ((size_t)rep * 4 + wave) * 16;
+    for (int i = 0; i < 16; i++) dbg[i] = st_acc[i];
+  }
+#endif
   // ------------------------------------------------------------------ epilogue
   if (MODE == 0 && wave == 0) {
 #pragma unroll
@@ -586,9 +709,10 @@ static int em_chunks(int E) { return E <= 64 ? 1 : (E <= 128 ? 2 : 4); }
 size_t colate_em_lds_bytes(int E, int A) {
   const size_t EPAD = (size_t)em_chunks(E) * kWave;
   const size_t AP = (size_t)em_threads(A);
+  const size_t APZ = AP + 16;
   const size_t nwaves = AP / kWave;
-  const size_t doubles = (EPAD + 1) + nwaves * kNumGather * EPAD + 2 * kNumBinArrays * AP + 8;
-  const size_t ints = (AP + 1) + 4;
+  const size_t doubles = (EPAD + 1) + nwaves * kNumGather * EPAD + 2 * kNumBinArrays * APZ + 6 * APZ + 8;
+  const size_t ints = (AP + 1) + 8 + 4;
   return doubles * sizeof(double) + ints * sizeof(int);
 }
 

@@ -27,37 +27,77 @@ namespace em {
 
 EM_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-// exp(x), |error| <= ~0.52 ulp.  x may be any finite value or -inf; large
-// negative arguments underflow gradually to 0 through ldexp.
-EM_HD double em_exp(double x) {
+// Core of exp(): for xc >= -1100 returns y and k with exp(xc) = y * 2^k, y in [0.70, 1.42), and the
+// pieces (rh, tp) of exp(rh) - 1 = rh + tp that 1 - exp() needs near 0.  The polynomial is
+// evaluated Estrin-style (depth 5 instead of 12: the EM kernel is a chain of dependent
+// instructions run by one wave per SIMD, so depth is what costs).
+struct ExpParts {
+  double y, k, rh, tp;
+};
+EM_HD ExpParts em_exp_parts(double xc) {
   const double LOG2E = 0x1.71547652b82fep+0;
   const double LN2_HI = 0x1.62e42fefa3800p-1;   // 42 significant bits: k*LN2_HI is exact
   const double LN2_LO = 0x1.ef35793c76730p-45;  // ln2 - LN2_HI
-  double xc = x > -1100.0 ? x : -1100.0;        // keeps k in range; exp(-1100) == 0 anyway
-  double k = __builtin_rint(xc * LOG2E);
-  double rh = fma_(-k, LN2_HI, xc);  // exact
-  double rl = -k * LN2_LO;           // |rl| < 1e-10
+  ExpParts o;
+  o.k = __builtin_rint(xc * LOG2E);
+  const double rh = fma_(-o.k, LN2_HI, xc);  // exact
+  const double rl = -o.k * LN2_LO;           // |rl| < 1e-10
   // exp(rh) = 1 + rh + rh^2 * (1/2 + rh * P(rh)),  P = 1/3! + rh/4! + ... + rh^11/14!
-  double p = 0x1.93974a8c07c9dp-37;         // 1/14!
-  p = fma_(p, rh, 0x1.6124613a86d09p-33);   // 1/13!
-  p = fma_(p, rh, 0x1.1eed8eff8d898p-29);   // 1/12!
-  p = fma_(p, rh, 0x1.ae64567f544e4p-26);   // 1/11!
-  p = fma_(p, rh, 0x1.27e4fb7789f5cp-22);   // 1/10!
-  p = fma_(p, rh, 0x1.71de3a556c734p-19);   // 1/9!
-  p = fma_(p, rh, 0x1.a01a01a01a01ap-16);   // 1/8!
-  p = fma_(p, rh, 0x1.a01a01a01a01ap-13);   // 1/7!
-  p = fma_(p, rh, 0x1.6c16c16c16c17p-10);   // 1/6!
-  p = fma_(p, rh, 0x1.1111111111111p-7);    // 1/5!
-  p = fma_(p, rh, 0x1.5555555555555p-5);    // 1/4!
-  p = fma_(p, rh, 0x1.5555555555555p-3);    // 1/3!
-  double r2 = rh * rh;
-  double t = r2 * fma_(p, rh, 0.5);  // rh^2/2 + rh^3 P(rh): |t| < 0.07, abs error ~1e-18
-  double s1 = 1.0 + rh;              // Fast2Sum (|1| > |rh|): s1 + e1 == 1 + rh exactly
-  double e1 = rh - (s1 - 1.0);
-  t = t + fma_(rl, s1 + t, e1);      // + rl * exp(rh), + the bits lost in 1 + rh
-  double y = s1 + t;
-  y = __builtin_ldexp(y, (int)k);
+  const double r2 = rh * rh;
+  const double r4 = r2 * r2;
+  const double r8 = r4 * r4;
+  const double a0 = fma_(0x1.5555555555555p-5, rh, 0x1.5555555555555p-3);    // 1/3! + r/4!
+  const double a1 = fma_(0x1.6c16c16c16c17p-10, rh, 0x1.1111111111111p-7);   // 1/5! + r/6!
+  const double a2 = fma_(0x1.a01a01a01a01ap-16, rh, 0x1.a01a01a01a01ap-13);  // 1/7! + r/8!
+  const double a3 = fma_(0x1.27e4fb7789f5cp-22, rh, 0x1.71de3a556c734p-19);  // 1/9! + r/10!
+  const double a4 = fma_(0x1.1eed8eff8d898p-29, rh, 0x1.ae64567f544e4p-26);  // 1/11! + r/12!
+  const double a5 = fma_(0x1.93974a8c07c9dp-37, rh, 0x1.6124613a86d09p-33);  // 1/13! + r/14!
+  const double b0 = fma_(a1, r2, a0);
+  const double b1 = fma_(a3, r2, a2);
+  const double b2 = fma_(a5, r2, a4);
+  const double p = fma_(b2, r8, fma_(b1, r4, b0));
+  const double tp = r2 * fma_(p, rh, 0.5);  // rh^2/2 + rh^3 P(rh): |tp| < 0.07, abs error ~1e-18
+  const double s1 = 1.0 + rh;               // Fast2Sum (|1| > |rh|): s1 + e1 == 1 + rh exactly
+  const double e1 = rh - (s1 - 1.0);
+  const double t = tp + fma_(rl, s1 + tp, e1);  // + rl * exp(rh), + the bits lost in 1 + rh
+  o.y = s1 + t;
+  o.rh = rh;
+  o.tp = tp;
+  return o;
+}
+
+// exp(x), |error| <= ~0.52 ulp.  x may be any finite value or -inf; large
+// negative arguments underflow gradually to 0 through ldexp.
+EM_HD double em_exp(double x) {
+  const double xc = x > -1100.0 ? x : -1100.0;  // keeps k in range; exp(-1100) == 0 anyway
+  const ExpParts o = em_exp_parts(xc);
+  const double y = __builtin_ldexp(o.y, (int)o.k);
   return (x != x) ? x : y;  // NaN in -> NaN out (the max() above would have dropped it)
+}
+
+// exp(x) and 1 - exp(x) for x <= 0, the latter without cancellation near 0 (|error| <= ~1 ulp).
+EM_HD double em_exp_om(double x, double* one_minus) {
+  const double xc = x > -1100.0 ? x : -1100.0;
+  const ExpParts o = em_exp_parts(xc);
+  const double y = __builtin_ldexp(o.y, (int)o.k);
+  const double om = (o.k == 0.0) ? -(o.rh + o.tp) : 1.0 - y;
+  *one_minus = (x != x) ? x : om;
+  return (x != x) ? x : y;
+}
+
+// 1/x for finite x > 0 within ~1 ulp (not correctly rounded): hardware seed + two Newton steps.
+// Used only where the reference has no division of its own (normalising constants).
+EM_HD double em_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma_(-x, y, 1.0);
+  y = fma_(y, e, y);
+  e = fma_(-x, y, 1.0);
+  y = fma_(y, e, y);
+  return y;
+#else
+  return 1.0 / x;
+#endif
 }
 
 // log(x) for finite x > 0 (normal or subnormal); <= ~1 ulp.  Only feeds the
