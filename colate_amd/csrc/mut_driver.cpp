@@ -35,7 +35,9 @@ namespace {
 // ------------------------------------------------------------------ options
 // Same option names as Colate.cpp:11-45 (unknown options are an error there too:
 // cxxopts throws option_not_exists_exception).  `--num_bootstrap` (README spelling)
-// is accepted as an alias of `--num_bootstraps`; `--device` is ours.
+// is accepted as an alias of `--num_bootstraps`.  Ours: `--device N` (GPU ordinal),
+// `--counts_out FILE` (write the bootstrap count tables in the reference's .colate_mat layout,
+// 17 significant digits) and `--counts_only` (stop after that; needs no GPU).
 struct Options {
   std::map<std::string, std::string> kv;
   bool has(const std::string& k) const { return kv.count(k) > 0; }
@@ -47,8 +49,8 @@ const char* const kValueOptions[] = {
     "target_table", "target_bam", "reference_bam", "target_tmp", "reference_tmp", "target_age",
     "reference_age", "ref_genome", "anc_genome", "mask", "mask_cutoff", "chr", "bins",
     "lineage_bin", "outgroup_tmrca", "years_per_gen", "coal", "seed", "num_bootstraps", "filters",
-    "groups", "poplabels", "map", "input", "output", "device"};
-const char* const kBoolOptions[] = {"help", "strandfilter"};
+    "groups", "poplabels", "map", "input", "output", "device", "counts_out"};
+const char* const kBoolOptions[] = {"help", "strandfilter", "counts_only"};
 
 bool parse_options(int argc, char** argv, Options& o, std::string& err) {
   for (int i = 1; i < argc; i++) {
@@ -115,6 +117,8 @@ void print_help() {
             << "      --seed arg             Optional: Seed for random number generator (int)\n"
             << "      --num_bootstraps arg   Optional: Number of bootstraps.\n"
             << "      --device arg           Optional (colate_amd): GPU ordinal, default 0.\n"
+            << "      --counts_out arg       Optional (colate_amd): write the bootstrap count tables (.colate_mat layout).\n"
+            << "      --counts_only          Optional (colate_amd): stop after --counts_out (no GPU needed).\n"
             << "  -o, --output arg           Filename of output.\n"
             << std::endl;
 }
@@ -545,6 +549,24 @@ int run_mut(const Options& opt) {
                  "existing <output>.colate_mat; BCF/BAM inputs go through `Colate --mode make_tmp` first."
               << std::endl;
     return 1;
+  }
+
+  if (opt.has("counts_out")) {  // same layout as the reference's .colate_mat (coal.cpp:3336-3343, 3453-3469)
+    FILE* f = std::fopen(opt.get("counts_out").c_str(), "w");
+    if (!f) {
+      std::cerr << "Error: cannot write " << opt.get("counts_out") << std::endl;
+      return 1;
+    }
+    for (int b = 0; b < A; b++) std::fprintf(f, "%.17g ", age_grid[b]);
+    std::fprintf(f, "\n");
+    for (int i = 0; i < B; i++) {
+      for (int b = 0; b < A; b++) std::fprintf(f, "%.17g ", csh[(size_t)i * A + b]);
+      std::fprintf(f, "\n");
+      for (int b = 0; b < A; b++) std::fprintf(f, "%.17g ", cns[(size_t)i * A + b]);
+      std::fprintf(f, "\n");
+    }
+    std::fclose(f);
+    if (opt.has("counts_only")) return 0;
   }
 
   // ---- epochs (coal.cpp:3501-3646)

@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ from the REFERENCE ITSELF.
+
+Runs only where /root/reference exists (this container): oracle/Makefile compiles the
+reference's own sources into oracle/_ref/ (libref_em.so = class coal_EM behind our extern "C"
+shim; Colate_ref = its `Colate` CLI) and this script records inputs + outputs:
+
+  l1_estep.json     coal_EM::EM_shared / EM_notshared (coal_EM.cpp:153-468) on grids of
+                    (epochs, rates, age): logl, num[E], denom[E] as hex floats (bit-exact)
+  l2_em_*.json      count tables -> `Colate_ref --mode mut` through its .colate_mat hook
+                    (coal.cpp:3169-3170, 3471-3499): .coal text and "Total iterations" per replicate
+  l3_*/             synthetic .mut(.gz) + .colate.in + chr.txt inputs (tests/synth_files.py) and the
+                    .coal the reference CLI writes for them with --seed (full path: readers, age
+                    sampling, block bootstrap, F redistribution, epochs, EM, writer)
+
+The fixtures are data (inputs and expected outputs); no reference source is copied.
+    python tests/golden/make_golden.py
+"""
+import gzip
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import oracle_lib as ol  # noqa: E402
+import synth_files  # noqa: E402
+from colate_amd import workloads  # noqa: E402
+
+REF_BIN = ol.COLATE_REF_BIN
+
+
+def hexes(a):
+    return [float(x).hex() for x in np.atleast_1d(a)]
+
+
+def run_ref(args, cwd):
+    r = subprocess.run([REF_BIN] + args, cwd=cwd, capture_output=True)  # bytes: text mode would turn \r into \n
+    stderr = r.stderr.decode()
+    assert r.returncode == 0, stderr[-2000:]
+    # progress messages end in "\r", the final one per replicate (coal.cpp:3823) in "\n"
+    iters = []
+    for line in stderr.split("\n"):
+        m = re.match(r"Bootstrap (\d+): Total iterations (\d+)$", line.split("\r")[-1])
+        if m:
+            iters.append(int(m.group(2)))
+    return stderr.replace("\r", "\n"), iters
+
+
+def make_l1():
+    assert ol.REF is not None, "oracle/_ref/libref_em.so missing: make -C oracle ref"
+    rng = np.random.default_rng(2024)
+    cases = []
+    grid = ol.age_grid()
+    for bins in ("3,7,0.2", "2,7.95,0.05"):
+        ep, _ = ol.epochs_from_bins(bins)
+        E = ep.size
+        rate_sets = [np.full(E, 1.0 / 20000.0), np.full(E, 1e-7), np.exp(rng.uniform(np.log(5e-9), np.log(1e-3), E))]
+        r = np.exp(rng.uniform(np.log(1e-6), np.log(1e-3), E))
+        r[0] = 0.0
+        r[3] = 5e-9
+        rate_sets.append(r)
+        ages = [0.0, grid[1], grid[30], grid[41], grid[64], grid[65], grid[90], grid[120], grid[150], grid[170],
+                grid[184], float(ep[5]), float(ep[E - 1])]
+        for rates in rate_sets:
+            for age in ages:
+                for kind in (0, 1):
+                    ll, num, den = ol.ref_em_call(kind, ep, rates, age)
+                    cases.append({"bins": bins, "kind": kind, "age": float(age).hex(), "rates": hexes(rates),
+                                  "logl": float(ll).hex(), "num": hexes(num), "denom": hexes(den)})
+    # the reference's own unit-test grid (include/test/test_aDNA.cpp:74-116): E = 21, constant rates
+    E = 21
+    ep = np.zeros(E)
+    ep[1] = 1e3 / 28.0
+    log10 = float(np.float32(np.log(10)))
+    for e in range(2, E - 1):
+        ep[e] = np.exp(log10 * (3.0 + 4.0 * (e - 1.0) / (E - 3.0))) / 28.0
+    ep[E - 1] = 1e8 / 28.0
+    for f in (1, 4, 7):
+        rates = np.full(E, 1e-7 * np.exp(np.log(10) * (f - 1)))
+        for b in range(0, 92, 7):
+            age = np.exp(b / 5.0) / 10.0
+            for kind in (0, 1):
+                ll, num, den = ol.ref_em_call(kind, ep, rates, age)
+                cases.append({"epochs": hexes(ep), "kind": kind, "age": float(age).hex(), "rates": hexes(rates),
+                              "logl": float(ll).hex(), "num": hexes(num), "denom": hexes(den)})
+    json.dump({"generator": "tests/golden/make_golden.py (oracle/_ref/libref_em.so)", "cases": cases},
+              open(os.path.join(HERE, "l1_estep.json"), "w"))
+    print("l1_estep.json:", len(cases), "cases")
+
+
+def make_l2():
+    grid = ol.age_grid()
+    for name, bins, B, nb, scale, ne2 in (("wg_e23", "3,7,0.2", 3, 115, 11.0, 12000.0),
+                                          ("chr1_e23", "3,7,0.2", 1, 9, 1.0, 12000.0),
+                                          ("wg_e122", "2,7.95,0.05", 2, 115, 11.0, 12000.0),
+                                          ("smallne_e23", "3,7,0.2", 2, 115, 11.0, 3000.0),
+                                          ("largene_e23", "3,7,0.2", 2, 115, 11.0, 2000000.0)):
+        csh, cns = workloads.bootstrap_tables(grid, B, nb=nb, scale=scale, ne2=ne2, seed=4242)
+        with tempfile.TemporaryDirectory() as d:
+            with open(os.path.join(d, "OUT.colate_mat"), "w") as f:
+                f.write(" ".join("%.17g" % x for x in grid) + "\n")
+                for b in range(B):
+                    f.write(" ".join("%.17g" % x for x in csh[b]) + "\n")
+                    f.write(" ".join("%.17g" % x for x in cns[b]) + "\n")
+            err, iters = run_ref(["--mode", "mut", "--mut", "dummy", "--bins", bins, "--num_bootstraps", str(B), "-o", "OUT"], d)
+            coal = open(os.path.join(d, "OUT.coal")).read()
+        assert len(iters) == B, err[-500:]
+        json.dump({"generator": "tests/golden/make_golden.py (oracle/_ref/Colate_ref, .colate_mat hook)", "bins": bins,
+                   "cnt_shared": [hexes(r) for r in csh], "cnt_notshared": [hexes(r) for r in cns],
+                   "coal": coal, "iterations": iters}, open(os.path.join(HERE, f"l2_em_{name}.json"), "w"))
+        print(f"l2_em_{name}.json: B={B} iterations={iters}")
+
+
+def make_l3():
+    cases = {
+        "l3_modern": dict(gen=dict(chroms=("1", "2"), snps_per_chr=1500, seed=7, gz=True),
+                          args=["--bins", "3,7,0.2", "--seed", "1", "--num_bootstraps", "3", "--chr", "chr.txt"]),
+        "l3_ancient": dict(gen=dict(chroms=("1", "2", "3"), snps_per_chr=800, seed=11, gz=True),
+                           args=["--bins", "3,7,0.2", "--seed", "5", "--num_bootstraps", "2", "--chr", "chr.txt",
+                                 "--target_age", "7000", "--reference_age", "0"]),
+        "l3_nochr": dict(gen=dict(chroms=("1",), snps_per_chr=1200, seed=3, gz=False, with_chr_file=False),
+                         args=["--bins", "3,6,0.5", "--seed", "9", "--num_bootstraps", "1"]),
+    }
+    for name, c in cases.items():
+        d = os.path.join(HERE, name)
+        shutil.rmtree(d, ignore_errors=True)
+        synth_files.write_inputs(d, **c["gen"])
+        mut_arg = "P" if c["gen"].get("with_chr_file", True) else "P.mut"
+        args = ["--mode", "mut", "--mut", mut_arg, "--target_tmp", "T.colate.in", "--reference_tmp", "R.colate.in"] + c["args"] + ["-o", "expected"]
+        err, iters = run_ref(args, d)
+        nblocks = int(re.search(r"Number of blocks: (\d+)", err).group(1))
+        json.dump({"generator": "tests/golden/make_golden.py (oracle/_ref/Colate_ref)", "args": args, "iterations": iters,
+                   "num_blocks": nblocks}, open(os.path.join(d, "case.json"), "w"))
+        for fn in ("T.colate.in", "R.colate.in"):  # keep the fixtures small
+            with open(os.path.join(d, fn), "rb") as f, gzip.GzipFile(os.path.join(d, fn + ".gz"), "wb", mtime=0) as g:
+                g.write(f.read())
+            os.remove(os.path.join(d, fn))
+        print(f"{name}: blocks={nblocks} iterations={iters}")
+
+
+if __name__ == "__main__":
+    assert os.path.exists(REF_BIN), "oracle/_ref/Colate_ref missing: make -C oracle ref (needs /root/reference)"
+    make_l1()
+    make_l2()
+    make_l3()

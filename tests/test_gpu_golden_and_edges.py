@@ -1,0 +1,185 @@
+"""GPU: the HIP path against the reference's own outputs (golden fixtures), the full drop-in CLI,
+edge cases and size-independent properties at BASELINE sizes.  All calls go through the C ABI."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_lib as gl
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "colate_amd", "bin", "Colate")
+RATE_RTOL = 1e-6  # north_star
+
+
+def _rel(a, b):
+    m = np.maximum(np.abs(a), np.abs(b))
+    m[m == 0] = 1.0
+    return np.abs(a - b) / m
+
+
+@pytest.fixture(scope="module")
+def ca():
+    import colate_amd
+
+    assert colate_amd.device_count() >= 1
+    return colate_amd
+
+
+def test_l1_golden_estep_through_coal_EM_mirror(ca):
+    """Golden vectors of coal_EM::EM_shared/EM_notshared recorded from the reference build."""
+    groups = {}
+    for c in gl.l1_cases():
+        key = (c["epochs"].tobytes(), c["rates"].tobytes(), c["kind"])
+        groups.setdefault(key, []).append(c)
+    checked = 0
+    for cases in groups.values():
+        ep, rates, kind = cases[0]["epochs"], cases[0]["rates"], cases[0]["kind"]
+        if kind == 1 and rates[-1] <= 0:
+            continue
+        ages = np.array([c["age"] for c in cases])
+        num, den, ll, flags = ca.coal_EM(ep, rates).EM_many(ages, kind == 0)
+        dt = np.append(np.diff(ep), 0.0)
+        for i, c in enumerate(cases):
+            if np.isnan(c["num"]).any() or np.isnan(c["denom"]).any():
+                continue  # the reference asserts (aborts) on these
+            assert abs(ll[i] - c["logl"]) <= 1e-9 * max(1.0, abs(c["logl"]))
+            assert (np.abs(num[i] - c["num"]) <= 1e-7 * np.abs(c["num"]) + 1e-300).all()
+            assert (np.abs(den[i] - c["denom"]) <= 1e-6 * np.abs(c["denom"]) + 1e-13 * dt + 1e-300).all()
+            checked += 1
+    assert checked > 200
+
+
+@pytest.mark.parametrize("name", gl.l2_names())
+def test_l2_golden_coal_text_and_iterations(ca, name):
+    """Same count tables as the reference run: identical 'Total iterations' and identical .coal text
+    (6 significant digits) wherever the reference's own digits are reproducible (stable_mask)."""
+    c = gl.l2_case(name)
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins(c["bins"])
+    rates, iters, ll, flags = ca.em_batch(grid, c["csh"], c["cns"], ep)
+    assert (flags == 0).all()
+    assert iters.tolist() == c["iterations"]
+    ref_rows = [np.array(line.split()[2:], dtype=np.float64) for line in c["coal"].split("\n")[2:] if line]
+    mine_rows = [np.array(("".join("%g " % x for x in r)).split(), dtype=np.float64) for r in rates]
+    r0, _, _, _ = ol.em_batch(grid, c["csh"], c["cns"], ep)
+    mask = ol.stable_mask(grid, c["csh"], c["cns"], ep, r0)
+    assert mask.mean() > 0.85
+    for b in range(len(ref_rows)):
+        assert np.array_equal(mine_rows[b][mask[b]], ref_rows[b][mask[b]])
+        assert _rel(rates[b], r0[b])[mask[b]].max() < RATE_RTOL
+
+
+@pytest.mark.parametrize("name", gl.l3_names())
+def test_l3_cli_drop_in(ca, name, tmp_path):
+    """`Colate --mode mut` of colate_amd on the reference's input files: byte-identical .coal."""
+    case = gl.l3_stage(name, str(tmp_path))
+    args = list(case["args"])
+    args[args.index("-o") + 1] = "mine"
+    r = subprocess.run([CLI] + args, cwd=str(tmp_path), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    err = r.stderr.decode()
+    got_iters = [int(l.rsplit(" ", 1)[1]) for l in err.split("\n") if l.startswith("Bootstrap ")]
+    assert got_iters == case["iterations"]
+    assert (tmp_path / "mine.coal").read_text() == (tmp_path / "expected.coal").read_text()
+
+
+def test_edge_cases(ca):
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins("3,7,0.2")
+    A, E = grid.size, ep.size
+    # B = 0 is a no-op
+    r, it, ll, fl = ca.em_batch(grid, np.zeros((0, A)), np.zeros((0, A)), ep)
+    assert r.shape == (0, E)
+    # empty count tables: every num is 0 -> all rates copy epoch 0 (= 0); the stop rule never fires
+    # (ll/prev = 0/0), so the cap ends the run, flagged -- exactly the oracle's behaviour
+    r, it, ll, fl = ca.em_batch(grid, np.zeros((2, A)), np.zeros((2, A)), ep, max_iter=1200)
+    r0, it0, ll0, fl0 = ol.em_batch(grid, np.zeros((2, A)), np.zeros((2, A)), ep, max_iter=1200)
+    assert np.array_equal(r, r0) and (it == it0).all() and (fl & 4).all() and (fl0 & 4).all()
+    # ragged: a single not-shared bin / a single shared bin / data only beyond the last epoch start
+    for kind, b in ((1, 100), (0, 100), (1, 180), (0, 60)):
+        csh, cns = np.zeros((1, A)), np.zeros((1, A))
+        (csh if kind == 0 else cns)[0, b] = 37.5
+        r, it, ll, fl = ca.em_batch(grid, csh, cns, ep, max_iter=1500)
+        r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep, max_iter=1500)
+        assert (it == it0).all()
+        m = ol.stable_mask(grid, csh, cns, ep, r0, max_iter=1500)
+        assert _rel(r, r0)[m].max() < RATE_RTOL
+    # minimal and maximal epoch counts, short age grids
+    from colate_amd import workloads
+
+    csh, cns = workloads.bootstrap_tables(grid, 2, nb=9, scale=1.0)
+    for e_arr in (np.array([0.0, 1e3]), np.concatenate([[0.0], np.geomspace(30, 3e5, 254), [4e6]])):
+        r, it, ll, fl = ca.em_batch(grid, csh, cns, e_arr, max_iter=1100)
+        r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, e_arr, max_iter=1100)
+        assert (it == it0).all() and np.allclose(ll, ll0, rtol=1e-11, atol=0)
+        m = ol.stable_mask(grid, csh, cns, e_arr, r0, max_iter=1100)
+        assert _rel(r, r0)[m].max() < RATE_RTOL
+    sub = slice(40, 151)
+    r, it, ll, fl = ca.em_batch(grid[sub], csh[:, sub], cns[:, sub], ep)
+    r0, it0, ll0, fl0 = ol.em_batch(grid[sub], csh[:, sub], cns[:, sub], ep)
+    assert (it == it0).all() and _rel(r, r0).max() < 1e-8
+    # warm start (--coal): starting rates given per epoch
+    init = np.exp(np.random.default_rng(3).uniform(np.log(1e-6), np.log(1e-3), E))
+    r, it, ll, fl = ca.em_batch(grid, csh, cns, ep, init_rates=init)
+    r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep, init=init)
+    m = ol.stable_mask(grid, csh, cns, ep, r0, init=init)
+    assert (it == it0).all() and _rel(r, r0)[m].max() < RATE_RTOL
+
+
+def test_properties_at_baseline_sizes(ca):
+    """Size-independent properties at configs[2]/[4] scale (1000 and 2000 replicates in one launch)."""
+    from colate_amd import workloads
+
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins("3,7,0.2")
+    csh, cns = workloads.bootstrap_tables(grid, 1000)
+    r, it, ll, fl = ca.em_batch(grid, csh, cns, ep)
+    assert (fl == 0).all() and (it >= 1001).all() and np.isfinite(r).all() and (r >= 0).all()
+    # determinism: the same launch twice is bit-identical
+    r2, it2, ll2, _ = ca.em_batch(grid, csh, cns, ep)
+    assert np.array_equal(r, r2) and np.array_equal(ll, ll2) and (it == it2).all()
+    # replicates are independent: any permutation / duplication of rows permutes / duplicates results bit for bit
+    perm = np.random.default_rng(0).permutation(1000)
+    big_sh, big_ns = np.concatenate([csh[perm], csh]), np.concatenate([cns[perm], cns])
+    rp, itp, llp, _ = ca.em_batch(grid, big_sh, big_ns, ep)
+    assert np.array_equal(rp[:1000], r[perm]) and np.array_equal(rp[1000:], r) and (itp[:1000] == it[perm]).all()
+    # spot-check against the oracle
+    idx = [0, 499, 999]
+    r0, it0, ll0, _ = ol.em_batch(grid, csh[idx], cns[idx], ep)
+    assert (it[idx] == it0).all() and _rel(r[idx], r0).max() < 1e-8
+    # scaling every count by 2 is exact in binary: same rates bit for bit, log-likelihood doubled
+    rs, its, lls, _ = ca.em_batch(grid, 2 * csh[:8], 2 * cns[:8], ep)
+    assert np.array_equal(rs, r[:8]) and np.array_equal(lls, 2 * ll[:8])
+
+
+def test_device_entry_points_with_torch(ca):
+    """colate_em_batch_device / colate_em_estep_device on tensors resident in HBM, on a side stream,
+    with per-replicate epochs and starting rates (batched all-pairs layout)."""
+    import torch
+    from colate_amd import workloads
+
+    grid = ol.age_grid()
+    ep_a, _ = ol.epochs_from_bins("3,7,0.2")
+    ep_b = ep_a.copy()
+    ep_b[2:-1] *= 1.1
+    csh, cns = workloads.bootstrap_tables(grid, 4, nb=9, scale=1.0)
+    dev = torch.device("cuda")
+    f64 = dict(dtype=torch.float64, device=dev)
+    eps = torch.tensor(np.stack([ep_a, ep_b, ep_a, ep_b]), **f64)
+    init = torch.full((4, ep_a.size), 1.0 / 20000.0, **f64)
+    out = torch.empty((4, ep_a.size), **f64)
+    it = torch.empty(4, dtype=torch.int32, device=dev)
+    ll = torch.empty(4, **f64)
+    fl = torch.empty(4, dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ca.em_batch_device(torch.tensor(grid, **f64), torch.tensor(csh, **f64), torch.tensor(cns, **f64), eps, init,
+                           out, it, ll, fl, stream=s)
+    s.synchronize()
+    for b, e in enumerate((ep_a, ep_b, ep_a, ep_b)):
+        r0, it0, _, _ = ol.em_batch(grid, csh[b:b + 1], cns[b:b + 1], e)
+        assert int(it[b]) == it0[0] and _rel(out[b].cpu().numpy(), r0[0]).max() < 1e-8

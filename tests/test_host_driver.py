@@ -1,0 +1,166 @@
+"""Host side of the drop-in (C ABI + `Colate` command line) on the CPU: symbol table, the pieces of
+mut() around the EM (age grid, epochs, block bootstrap + F redistribution, .coal writer, readers) and
+the full CLI up to the count tables, checked against the oracle and the golden fixtures."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_lib as gl
+import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "colate_amd", "bin", "Colate")
+
+
+@pytest.fixture(scope="module")
+def ca():
+    import colate_amd
+
+    return colate_amd
+
+
+def test_library_exports_every_declared_symbol(ca):
+    header = open(os.path.join(ROOT, "include", "colate_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(colate_[a-z_]+)\s*\(", header))
+    assert len(declared) >= 15
+    from colate_amd._lib import SIGNATURES, lib
+
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/colate_amd.h but not exported"
+    assert declared == set(SIGNATURES), declared ^ set(SIGNATURES)
+    assert "gfx950" in ca.version()
+
+
+def test_no_cpu_fallback(ca):
+    """Without a HIP device the compute entry points must fail loudly (never compute on the CPU)."""
+    if ca.device_count() > 0:
+        pytest.skip("a GPU is present")
+    grid = ca.age_grid()
+    ep, _ = ca.epochs_from_bins("3,7,0.2")
+    with pytest.raises(ca.ColateError) as e:
+        ca.em_batch(grid, np.ones((1, grid.size)), np.ones((1, grid.size)), ep)
+    assert e.value.code == -2
+    with pytest.raises(ca.ColateError):
+        ca.em_estep(grid, np.ones((1, grid.size)), np.ones((1, grid.size)), ep, np.full((1, ep.size), 1e-4))
+
+
+def test_argument_validation(ca):
+    grid = ca.age_grid()
+    ep, _ = ca.epochs_from_bins("3,7,0.2")
+    one = np.ones((1, grid.size))
+    with pytest.raises(ca.ColateError) as e:  # unsorted epochs
+        ca.em_batch(grid, one, one, ep[::-1].copy())
+    assert e.value.code == -1
+    with pytest.raises(ca.ColateError) as e:  # too many epochs
+        ca.em_batch(grid, one, one, np.arange(300.0))
+    assert e.value.code == -4
+    with pytest.raises(ca.ColateError):  # bad --bins
+        ca.epochs_from_bins("3,7")
+
+
+def test_age_grid_matches_oracle(ca):
+    g = ca.age_grid()
+    assert g.size == 185 and np.array_equal(g, ol.age_grid())
+    assert g[0] == 0.0 and g[1] == 0.1 and g[184] == np.exp(18.3) / 10.0
+
+
+@pytest.mark.parametrize("bins", ["3,7,0.2", "2,7.95,0.05", "3,6,0.5", "2.5,7,0.3", "4,6.1,0.7"])
+@pytest.mark.parametrize("age_years", [0.0, 500.0, 1000.0, 1200.0, 7000.0, 45000.0])
+def test_epochs_from_bins_matches_oracle(ca, bins, age_years):
+    age = age_years / 28.0
+    e1, n1 = ca.epochs_from_bins(bins, age, 28.0)
+    e0, n0 = ol.epochs_from_bins(bins, age, 28.0)
+    assert n1 == n0 and np.array_equal(e1, e0)
+    assert e1[0] == 0.0 and np.all(np.diff(e1) >= 0)
+
+
+def test_epochs_23_and_122(ca):
+    assert ca.epochs_from_bins("3,7,0.2")[0].size == 23     # BASELINE configs[0..2]
+    assert ca.epochs_from_bins("2,7.95,0.05")[0].size == 122  # configs[3] (2,8,0.05 aborts the reference)
+
+
+def test_block_bootstrap_matches_oracle_and_restated_rng(ca):
+    """std::mt19937 + uniform_int_distribution in the product vs the oracle's restatement of both
+    (Matsumoto-Nishimura + libstdc++-11 Lemire), then the weighted sums and the F redistribution."""
+    rng = np.random.default_rng(5)
+    grid = ol.age_grid()
+    A, nb, B = grid.size, 17, 6
+    sh = rng.uniform(0, 3, (nb, A)) * (rng.uniform(size=(nb, A)) < 0.6)
+    ns = rng.uniform(0, 9, (nb, A)) * (rng.uniform(size=(nb, A)) < 0.6)
+    she = rng.uniform(0, 1, (nb, A)) * (rng.uniform(size=(nb, A)) < 0.2)
+    nse = rng.uniform(0, 1, (nb, A)) * (rng.uniform(size=(nb, A)) < 0.2)
+    for age in (0.0, 250.0):
+        for nboot in (1, B):
+            c_sh, c_ns = ca.bootstrap_counts(ca.Rng(12345), nboot, grid, age, sh, ns, she, nse)
+            g = (ctypes.c_uint * 625)()
+            ol.O.oracle_mt_seed(g, 12345)
+            for i in range(nboot):
+                w = np.zeros(nb)
+                ol.O.oracle_block_weights(g, nb, nboot, ol.P(w))
+                o_sh, o_ns = np.zeros(A), np.zeros(A)
+                ol.O.oracle_bootstrap_counts(nb, A, ol.P(grid), age, ol.P(w), ol.P(sh), ol.P(ns), ol.P(she), ol.P(nse),
+                                             ol.P(o_sh), ol.P(o_ns))
+                assert np.array_equal(c_sh[i], o_sh) and np.array_equal(c_ns[i], o_ns)
+
+
+def test_write_coal_format(ca, tmp_path):
+    ep = np.array([0.0, 35.7142857, 56.6033287, 1e5 / 3, 3571428.5714285714])
+    rates = np.array([[0.0, 6.66486e-05, 5e-9, 1.23456789e-7, 5e-05], [0.0, 1e-4, 2e-4, 3e-4, 4e-4]])
+    p = tmp_path / "x.coal"
+    ca.write_coal(p, ep, rates)
+    assert p.read_text() == gl.coal_text(ep, rates)
+    assert p.read_text().split("\n")[1] == "0 35.7143 56.6033 33333.3 3.57143e+06 "
+    ca.write_coal(p, ep, rates, is_ancient=True, ep_null=1)
+    assert p.read_text() == gl.coal_text(ep, rates, True, 1)
+    # and back: --coal gives epochs (through std::stof) and starting rates
+    ca.write_coal(p, ep, rates[:1])
+    e2, r2 = ca.epochs_from_coal(p)
+    assert np.array_equal(e2, np.array([float(np.float32(float("%g" % x))) for x in ep]))
+    assert np.array_equal(r2, np.array([float("%g" % x) for x in rates[0]]))
+
+
+def _run_cli(args, cwd):
+    return subprocess.run([CLI] + args, cwd=cwd, capture_output=True)
+
+
+@pytest.mark.parametrize("name", gl.l3_names())
+def test_cli_feeder_and_bootstrap_reproduce_reference(name, tmp_path):
+    """Full host path of `Colate --mode mut` (.mut/.colate.in readers, age sampling from the shared
+    mt19937, 30-Mb blocks, block bootstrap, F redistribution) -> count tables; the oracle's EM on those
+    tables must print exactly the .coal the reference CLI printed for the same files and --seed."""
+    case = gl.l3_stage(name, str(tmp_path))
+    args = [a for a in case["args"]]
+    args[args.index("-o") + 1] = "mine"
+    B = int(args[args.index("--num_bootstraps") + 1])
+    r = _run_cli(args + ["--counts_out", "mine.counts", "--counts_only"], str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    assert f"Number of blocks: {case['num_blocks']}" in r.stderr.decode()
+    grid, csh, cns = gl.read_counts(tmp_path / "mine.counts", B)
+    assert np.array_equal(grid, ol.age_grid())
+    age = 0.0
+    if "--target_age" in args:
+        age = max(float(np.float32(args[args.index("--target_age") + 1])),
+                  float(np.float32(args[args.index("--reference_age") + 1]))) / 28.0
+    ep, ep_null = ol.epochs_from_bins(args[args.index("--bins") + 1], age, 28.0)
+    rates, iters, ll, fl = ol.em_batch(grid, csh, cns, ep)
+    assert iters.tolist() == case["iterations"]
+    assert gl.coal_text(ep, rates, age > 0, ep_null) == (tmp_path / "expected.coal").read_text()
+
+
+def test_cli_option_errors(tmp_path):
+    r = _run_cli(["--mode", "mut", "--nonsense", "1"], str(tmp_path))
+    assert r.returncode != 0 and b"does not exist" in r.stderr
+    r = _run_cli(["--mode", "mut"], str(tmp_path))
+    assert b"Not enough arguments supplied." in r.stdout
+    r = _run_cli(["--mode", "make_tmp"], str(tmp_path))
+    assert r.returncode != 0
+    # README spelling --num_bootstrap is accepted (the reference only knows --num_bootstraps)
+    case = gl.l3_stage("l3_nochr", str(tmp_path))
+    args = [("--num_bootstrap" if a == "--num_bootstraps" else a) for a in case["args"]]
+    r = _run_cli(args + ["--counts_out", "c.txt", "--counts_only"], str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-500:]
