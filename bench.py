@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicates", type=int, default=B_PER_GPU, help="bootstrap replicates per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive (host-pointer ABI) timing")
     args = ap.parse_args()
 
     import torch
@@ -209,6 +210,15 @@ def main():
                         "(2*A + E)*8 B per replicate, so the real limiter is FP64 VALU latency (DESIGN.md §5)",
             },
         }
+        if world == 1 and not args.no_host_path:
+            # PCIe-inclusive rate through the host-pointer entry point (hipMalloc + copies + launch + copies
+            # back inside the call); reported beside `value`, never as it
+            colate_amd.em_batch(grid, csh, cns, epochs)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                colate_amd.em_batch(grid, csh, cns, epochs)
+            out["host_path"] = {"value": 5 * B / (time.perf_counter() - t1), "unit": "replicates/s",
+                                "note": "colate_em_batch with host buffers, PCIe and allocation inclusive"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(grid, csh, cns, epochs, rates, iters)
         print(json.dumps(out), flush=True)
