@@ -58,12 +58,12 @@ int main(int argc, char** argv) {
   hipMemcpy(dbg.data(), d_dbg, dbg.size() * 8, hipMemcpyDeviceToHost);
   hipMemcpy(it.data(), d_it, B * 4, hipMemcpyDeviceToHost);
   printf("launch: %s, %.3f ms (stamped build), iters[0]=%d\n", hipGetErrorString(err), ms, it[0]);
-  const char* names[16] = {"ep: scan+lds write", "bin math", "seg-reduce+store", "barrier", "acc: N,D", "M-step", "-", "loop top/stop",
-                           "ep: cs chain", "ep: exp/div", "acc: tail loads", "acc: suffix sums", "acc: affine scan", "-", "-", "-"};
-  for (int w = 0; w < 1; w++) {
+  const char* names[16] = {"P2 start (gathers)", "P2 bin math", "P2 seg-reduce+store", "barrier 2", "P3 N,D + store", "P4 M-step", "-", "loop top/stop",
+                           "P1 cs scan", "P1 exp/div/write", "P3 tail loads", "P3 suffix scan (A)", "P3 affine scan (B)", "-", "-", "-"};
+  for (int w = 0; w < 2; w++) {
     unsigned long long tot = 0;
     for (int i = 0; i < 16; i++) tot += dbg[(size_t)w * 16 + i];
-    printf("replicate 0 wave %d: total %llu cycles, %.0f per iteration\n", w, tot, (double)tot / (it[0] + 1));
+    printf("replicate 0 role %d leader: total %llu cycles, %.0f per iteration\n", w, tot, (double)tot / (it[0] + 1));
     for (int i = 0; i < 16; i++)
       if (dbg[(size_t)w * 16 + i])
         printf("   %-20s %8.0f cyc/iter  %5.1f%%\n", names[i], (double)dbg[(size_t)w * 16 + i] / (it[0] + 1), 100.0 * dbg[(size_t)w * 16 + i] / tot);

@@ -85,7 +85,7 @@ __global__ void k(double* out, unsigned long long* cyc, int nthreads_active) {
 int main() {
   double* out; unsigned long long* cyc;
   hipMalloc(&out, 1024 * 8); hipMalloc(&cyc, 64);
-  for (int threads : {64, 256, 512}) {
+  for (int threads : {256, 64, 128, 192, 256, 320, 384, 448, 512, 768, 1024}) {
     hipMemset(cyc, 0, 64);
     k<<<1, threads>>>(out, cyc, threads);
     hipDeviceSynchronize();
