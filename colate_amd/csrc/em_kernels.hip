@@ -70,31 +70,43 @@ constexpr int ROW_SHR1 = 0x111, ROW_SHR2 = 0x112, ROW_SHR4 = 0x114, ROW_SHR8 = 0
 constexpr int ROW_SHL1 = 0x101, ROW_SHL2 = 0x102, ROW_SHL4 = 0x104, ROW_SHL8 = 0x108;
 constexpr int ROW_BCAST15 = 0x142, ROW_BCAST31 = 0x143, WAVE_SHR1 = 0x138, WAVE_SHL1 = 0x130;
 
-// inclusive prefix sum over the 64 lanes
-__device__ __forceinline__ double wave_prefix_sum(double v) {
+// The epoch-level scans only need to span the lanes that hold epochs: `rows` = number of 16-lane
+// rows in use (uniform), so E <= 16 / <= 32 skip the cross-row steps.
+
+// inclusive prefix sum over the lanes of the first `rows` rows
+__device__ __forceinline__ double wave_prefix_sum(double v, int rows = 4) {
   v += dpp_d<ROW_SHR1>(0.0, v);
   v += dpp_d<ROW_SHR2>(0.0, v);
   v += dpp_d<ROW_SHR4>(0.0, v);
   v += dpp_d<ROW_SHR8>(0.0, v);
-  v += dpp_d<ROW_BCAST15, 0xa>(0.0, v);
-  v += dpp_d<ROW_BCAST31, 0xc>(0.0, v);
+  if (rows > 1) v += dpp_d<ROW_BCAST15, 0xa>(0.0, v);
+  if (rows > 2) v += dpp_d<ROW_BCAST31, 0xc>(0.0, v);
   return v;
 }
-// inclusive suffix sum over the 64 lanes (lane l: sum of lanes l..63)
-__device__ __forceinline__ double wave_suffix_sum(double v, int lane) {
+// inclusive suffix sum (lane l: sum of lanes l..), lanes beyond the rows in use must hold 0
+__device__ __forceinline__ double wave_suffix_sum(double v, int lane, int rows = 4) {
   v += dpp_d<ROW_SHL1>(0.0, v);
   v += dpp_d<ROW_SHL2>(0.0, v);
   v += dpp_d<ROW_SHL4>(0.0, v);
   v += dpp_d<ROW_SHL8>(0.0, v);
-  const double r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
-  const double s23 = r2 + r3, s123 = r1 + s23;
-  const int row = lane >> 4;
-  const double add = row == 0 ? s123 : (row == 1 ? s23 : (row == 2 ? r3 : 0.0));
-  return v + add;
+  if (rows > 1) {
+    const double r1 = readlane_d(v, 16);
+    double add = 0.0;
+    if (rows > 2) {
+      const double r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
+      const double s23 = r2 + r3, s123 = r1 + s23;
+      const int row = lane >> 4;
+      add = row == 0 ? s123 : (row == 1 ? s23 : (row == 2 ? r3 : 0.0));
+    } else {
+      add = (lane >> 4) == 0 ? r1 : 0.0;
+    }
+    v = v + add;
+  }
+  return v;
 }
 // inclusive prefix composition of the affine maps x -> a*x + b (lane order = application order):
 // afterwards (a, b) of lane l is f_l o ... o f_0
-__device__ __forceinline__ void wave_affine_scan(double& a, double& b) {
+__device__ __forceinline__ void wave_affine_scan(double& a, double& b, int rows = 4) {
 #define COLATE_AFF_STEP(CTRL, RM)                  \
   {                                                \
     const double as = dpp_d<CTRL, RM>(1.0, a);     \
@@ -106,8 +118,8 @@ __device__ __forceinline__ void wave_affine_scan(double& a, double& b) {
   COLATE_AFF_STEP(ROW_SHR2, 0xf)
   COLATE_AFF_STEP(ROW_SHR4, 0xf)
   COLATE_AFF_STEP(ROW_SHR8, 0xf)
-  COLATE_AFF_STEP(ROW_BCAST15, 0xa)
-  COLATE_AFF_STEP(ROW_BCAST31, 0xc)
+  if (rows > 1) COLATE_AFF_STEP(ROW_BCAST15, 0xa)
+  if (rows > 2) COLATE_AFF_STEP(ROW_BCAST31, 0xc)
 #undef COLATE_AFF_STEP
 }
 
@@ -311,11 +323,12 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
   __syncthreads();
   if (grp >= NB) return;  // waves without bins retire; later barriers count the remaining waves only
   const bool leader = (grp == 0);
+  constexpr int erows = 4;  // (skipping cross-row scan steps for E <= 32 behind uniform branches measured slower)
   const int nwave_live = 2 * NB;
   (void)nwave_live;
 
   int my_flags = 0;
-  bool wrote_fail = false;
+  bool wrote_fail = false, flag_set = false;
   const double thr = 1.0 - p.rel_tol;
   double ll = -__builtin_inf(), prev_ll = -__builtin_inf();  // coal.cpp:3685
   int iter = 0;
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         const double x = lam_e[c] * dt_e[c];
-        const double incl = wave_prefix_sum(x);
+        const double incl = wave_prefix_sum(x, erows);
         cs_e[c] = carry + dpp_d<WAVE_SHR1, 0xf, true>(0.0, incl);
         csn_e[c] = cs_e[c] + x;
         carry = carry + readlane_d(incl, 63);
@@ -350,7 +363,9 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
         for (int c = 0; c < NCH; c++) {
           const int e = c * kWave + lane;
           S_e[c] = em::em_exp_om(-cs_e[c], &omS_e[c]);  // omS = 1 - S_e = sum_{j<e} exp(A_ep[j])
+          const double inv = 1.0 / lam_e[c];
           if (ep_on[c]) {
+            s_ep[G_XA * EPAD + e] = (t_e[c] + inv) / inv;  // coal_EM.cpp:204 (kept as a division: X below cancels)
             s_ep[G_CS * EPAD + e] = cs_e[c];
             s_ep[G_S * EPAD + e] = S_e[c];
             s_ep[G_PW * EPAD + e] = omS_e[c];
@@ -375,7 +390,6 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
           if (ep_on[c]) {
             s_ep[G_LAM * EPAD + e] = lam_e[c];
             s_ep[G_INV * EPAD + e] = inv;
-            s_ep[G_XA * EPAD + e] = (t_e[c] + inv) / inv;  // coal_EM.cpp:204 (kept as a division: X below cancels)
             s_ep[G_P * EPAD + e] = p_e[c];
             s_ep[G_BETA * EPAD + e] = beta_e[c];
           }
@@ -470,7 +484,11 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
           s_cfail[role * APZ + pos] = fail ? cnt : 0.0;
         }
         wrote_fail = fail;
-        if (lane == 0) s_fail[wave] = any_fail ? 1 : 0;
+        if (any_fail != flag_set) {  // (uniform) publish the per-wave flag only when it changes
+          COLATE_COLD();
+          if (lane == 0) s_fail[wave] = any_fail ? 1 : 0;
+          flag_set = any_fail;
+        }
       }
       // sums over the run of equal-epoch bins inside each 16-lane row, left to right
 #define COLATE_SEG_STEP(CTRL, F)                              \
@@ -498,6 +516,8 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
     COLATE_STAMP(3)
     // ============================================================ P3: per-epoch sums (role leaders)
     if (leader) {
+      int anyf = 0;  // did a bin of this role fail this iteration? (loaded with the tails: one LDS wait)
+      for (int i = 0; i < NB; i++) anyf |= s_fail[2 * i + role];
       double w[NCH], oN[NCH], oD[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
@@ -526,8 +546,6 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
 #pragma unroll
       for (int c = 0; c < NCH; c++) Cn[c] = C0[c];
       {
-        int anyf = 0;
-        for (int i = 0; i < NB; i++) anyf |= s_fail[2 * i + role];
         if (anyf) {
           COLATE_COLD();
 #pragma unroll
@@ -547,7 +565,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
         double cR = 0.0;
 #pragma unroll
         for (int c = NCH - 1; c >= 0; c--) {
-          const double sR = wave_suffix_sum(w[c], lane);
+          const double sR = wave_suffix_sum(w[c], lane, erows);
           RSn[c] = cR + dpp_d<WAVE_SHL1, 0xf, true>(0.0, sR);
           cR = cR + readlane_d(sR, 0);
         }
@@ -579,7 +597,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           double a = ep_on[c] ? q_e[c] : 1.0, b = ep_on[c] ? w[c] : 0.0;
-          wave_affine_scan(a, b);
+          wave_affine_scan(a, b, erows);
           const double Tn = em::fma_(a, Tc, b);         // T_{e+1}
           T[c] = dpp_d<WAVE_SHR1, 0xf, false>(Tc, Tn);  // T_e (lane 0: carry-in)
           Tc = readlane_d(Tn, 63);
