@@ -172,6 +172,13 @@ def main():
 
     if rank == 0:
         esteps = int((iters.astype(np.int64) + 1).sum())  # E-steps executed per launch
+        traffic = None  # HBM bytes per launch from the PMC passes committed under profiles/ (same workload only)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj["workload"] == {"replicates": B, "epochs": int(E), "age_bins": int(A)}:
+                traffic = tj["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         bytes_per_rep_iter = 2 * A * 8 + A * 8 + 3 * E * 8  # 4992 B at E=23
         achieved = esteps * bytes_per_rep_iter / (kern_ms * 1e-3) / 1e9
         out = {
@@ -201,7 +208,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "kernel": "em_kernel<0>",
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_launch": esteps * bytes_per_rep_iter,
