@@ -75,6 +75,17 @@ static int check_grids(int E, int A, const double* age_grid, const double* epoch
 
 struct DevBuf {
   void* p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) {
+      if (p) (void)hipFree(p);
+      p = o.p;
+      o.p = nullptr;
+    }
+    return *this;
+  }
+  DevBuf(DevBuf&& o) noexcept : p(o.p) { o.p = nullptr; }
   ~DevBuf() {
     if (p) (void)hipFree(p);
   }
@@ -190,6 +201,90 @@ int colate_em_batch(int B, int E, int A, const double* age_grid, const double* c
   HIP_TRY(hipMemcpy(out_loglik, d_ll.p, B * sizeof(double), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(out_flags, d_flags.p, B * sizeof(int), hipMemcpyDeviceToHost));
   return COLATE_OK;
+}
+
+int colate_em_batch_sharded(int num_devices, const int* devices, int B, int E, int A,
+                            const double* age_grid, const double* cnt_shared,
+                            const double* cnt_notshared, const double* epochs,
+                            const double* init_rates, int max_iter, int min_iter, double rel_tol,
+                            double rate_floor, double* out_rates, int* out_iters, double* out_loglik,
+                            int* out_flags) {
+  if (num_devices < 1 || !devices) return fail(COLATE_EINVAL, "need at least one device");
+  if (int rc = check_sizes(B, E, A)) return rc;
+  if (!age_grid || !cnt_shared || !cnt_notshared || !epochs || !init_rates || !out_rates ||
+      !out_iters || !out_loglik || !out_flags)
+    return fail(COLATE_EINVAL, "NULL pointer argument");
+  if (int rc = check_grids(E, A, age_grid, epochs)) return rc;
+  if (int rc = ensure_device()) return rc;
+  int ndev_avail = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev_avail));
+  for (int d = 0; d < num_devices; d++)
+    if (devices[d] < 0 || devices[d] >= ndev_avail)
+      return fail(COLATE_EINVAL, "device ordinal %d out of range (%d devices)", devices[d], ndev_avail);
+  int prev_dev = 0;
+  HIP_TRY(hipGetDevice(&prev_dev));
+  struct Shard {
+    int lo = 0, n = 0;
+    hipStream_t stream = nullptr;
+    DevBuf grid, sh, ns, ep, init, rates, iters, ll, flags;
+  };
+  std::vector<Shard> shards(num_devices);
+  int rc = COLATE_OK;
+  const int base = B / num_devices, rem = B % num_devices;
+  // enqueue everything (copies in, kernel, copies out) on one stream per shard, then wait for all
+  for (int d = 0; d < num_devices && rc == COLATE_OK; d++) {
+    Shard& s = shards[d];
+    s.lo = d * base + (d < rem ? d : rem);
+    s.n = base + (d < rem ? 1 : 0);
+    if (s.n == 0) continue;
+    const size_t nA = (size_t)s.n * A, nE = (size_t)s.n * E;
+    auto step = [&](hipError_t e, const char* what) {
+      if (e != hipSuccess && rc == COLATE_OK) rc = hip_fail(e, what);
+      return e == hipSuccess;
+    };
+    if (!step(hipSetDevice(devices[d]), "hipSetDevice")) break;
+    if (!step(hipStreamCreate(&s.stream), "hipStreamCreate")) break;
+    bool ok = step(s.grid.alloc(A * sizeof(double)), "hipMalloc") && step(s.sh.alloc(nA * sizeof(double)), "hipMalloc") &&
+              step(s.ns.alloc(nA * sizeof(double)), "hipMalloc") && step(s.ep.alloc(E * sizeof(double)), "hipMalloc") &&
+              step(s.init.alloc(E * sizeof(double)), "hipMalloc") && step(s.rates.alloc(nE * sizeof(double)), "hipMalloc") &&
+              step(s.iters.alloc(s.n * sizeof(int)), "hipMalloc") && step(s.ll.alloc(s.n * sizeof(double)), "hipMalloc") &&
+              step(s.flags.alloc(s.n * sizeof(int)), "hipMalloc");
+    if (!ok) break;
+    ok = step(hipMemcpyAsync(s.grid.p, age_grid, A * sizeof(double), hipMemcpyHostToDevice, s.stream), "copy") &&
+         step(hipMemcpyAsync(s.sh.p, cnt_shared + (size_t)s.lo * A, nA * sizeof(double), hipMemcpyHostToDevice, s.stream), "copy") &&
+         step(hipMemcpyAsync(s.ns.p, cnt_notshared + (size_t)s.lo * A, nA * sizeof(double), hipMemcpyHostToDevice, s.stream), "copy") &&
+         step(hipMemcpyAsync(s.ep.p, epochs, E * sizeof(double), hipMemcpyHostToDevice, s.stream), "copy") &&
+         step(hipMemcpyAsync(s.init.p, init_rates, E * sizeof(double), hipMemcpyHostToDevice, s.stream), "copy");
+    if (!ok) break;
+    int r2 = colate_em_batch_device(s.n, E, A, s.grid.as<double>(), s.sh.as<double>(), s.ns.as<double>(),
+                                    s.ep.as<double>(), 0, s.init.as<double>(), 0, max_iter, min_iter, rel_tol,
+                                    rate_floor, s.rates.as<double>(), s.iters.as<int>(), s.ll.as<double>(),
+                                    s.flags.as<int>(), s.stream);
+    if (r2) {
+      rc = r2;
+      break;
+    }
+    ok = step(hipMemcpyAsync(out_rates + (size_t)s.lo * E, s.rates.p, nE * sizeof(double), hipMemcpyDeviceToHost, s.stream), "copy") &&
+         step(hipMemcpyAsync(out_iters + s.lo, s.iters.p, s.n * sizeof(int), hipMemcpyDeviceToHost, s.stream), "copy") &&
+         step(hipMemcpyAsync(out_loglik + s.lo, s.ll.p, s.n * sizeof(double), hipMemcpyDeviceToHost, s.stream), "copy") &&
+         step(hipMemcpyAsync(out_flags + s.lo, s.flags.p, s.n * sizeof(int), hipMemcpyDeviceToHost, s.stream), "copy");
+    if (!ok) break;
+  }
+  for (int d = 0; d < num_devices; d++) {  // always drain and release, also after an error
+    Shard& s = shards[d];
+    if (!s.stream) continue;
+    (void)hipSetDevice(devices[d]);
+    hipError_t e = hipStreamSynchronize(s.stream);
+    if (e != hipSuccess && rc == COLATE_OK) rc = hip_fail(e, "hipStreamSynchronize");
+    (void)hipStreamDestroy(s.stream);
+    s.grid = DevBuf();
+  }
+  for (int d = 0; d < num_devices; d++) {  // free on the owning device
+    (void)hipSetDevice(devices[d]);
+    shards[d] = Shard();
+  }
+  (void)hipSetDevice(prev_dev);
+  return rc;
 }
 
 int colate_em_estep(int B, int E, int A, const double* age_grid, const double* cnt_shared,

@@ -35,7 +35,8 @@ namespace {
 // ------------------------------------------------------------------ options
 // Same option names as Colate.cpp:11-45 (unknown options are an error there too:
 // cxxopts throws option_not_exists_exception).  `--num_bootstrap` (README spelling)
-// is accepted as an alias of `--num_bootstraps`.  Ours: `--device N` (GPU ordinal),
+// is accepted as an alias of `--num_bootstraps`.  Ours: `--device N` (GPU ordinal), `--devices N`
+// (shard the replicates over GPUs 0..N-1 of the node),
 // `--counts_out FILE` (write the bootstrap count tables in the reference's .colate_mat layout,
 // 17 significant digits) and `--counts_only` (stop after that; needs no GPU).
 struct Options {
@@ -49,7 +50,7 @@ const char* const kValueOptions[] = {
     "target_table", "target_bam", "reference_bam", "target_tmp", "reference_tmp", "target_age",
     "reference_age", "ref_genome", "anc_genome", "mask", "mask_cutoff", "chr", "bins",
     "lineage_bin", "outgroup_tmrca", "years_per_gen", "coal", "seed", "num_bootstraps", "filters",
-    "groups", "poplabels", "map", "input", "output", "device", "counts_out"};
+    "groups", "poplabels", "map", "input", "output", "device", "devices", "counts_out"};
 const char* const kBoolOptions[] = {"help", "strandfilter", "counts_only"};
 
 bool parse_options(int argc, char** argv, Options& o, std::string& err) {
@@ -117,6 +118,7 @@ void print_help() {
             << "      --seed arg             Optional: Seed for random number generator (int)\n"
             << "      --num_bootstraps arg   Optional: Number of bootstraps.\n"
             << "      --device arg           Optional (colate_amd): GPU ordinal, default 0.\n"
+            << "      --devices arg          Optional (colate_amd): shard the bootstrap replicates over GPUs 0..N-1.\n"
             << "      --counts_out arg       Optional (colate_amd): write the bootstrap count tables (.colate_mat layout).\n"
             << "      --counts_only          Optional (colate_amd): stop after --counts_out (no GPU needed).\n"
             << "  -o, --output arg           Filename of output.\n"
@@ -600,10 +602,25 @@ int run_mut(const Options& opt) {
   }
   std::vector<double> rates((size_t)B * E), ll(B);
   std::vector<int> iters(B), flags(B);
-  int rc = colate_em_batch(B, E, A, age_grid.data(), csh.data(), cns.data(), epochs.data(),
-                           init_rates.data(), COLATE_DEFAULT_MAX_ITER, COLATE_DEFAULT_MIN_ITER,
-                           COLATE_DEFAULT_REL_TOL, COLATE_DEFAULT_RATE_FLOOR, rates.data(),
-                           iters.data(), ll.data(), flags.data());
+  int rc;
+  if (opt.has("devices")) {
+    const int nd = std::stoi(opt.get("devices"));
+    if (nd < 1) {
+      std::cerr << "Error: --devices must be at least 1." << std::endl;
+      return 1;
+    }
+    std::vector<int> devs(nd);
+    for (int d = 0; d < nd; d++) devs[d] = d;
+    rc = colate_em_batch_sharded(nd, devs.data(), B, E, A, age_grid.data(), csh.data(), cns.data(),
+                                 epochs.data(), init_rates.data(), COLATE_DEFAULT_MAX_ITER,
+                                 COLATE_DEFAULT_MIN_ITER, COLATE_DEFAULT_REL_TOL, COLATE_DEFAULT_RATE_FLOOR,
+                                 rates.data(), iters.data(), ll.data(), flags.data());
+  } else {
+    rc = colate_em_batch(B, E, A, age_grid.data(), csh.data(), cns.data(), epochs.data(),
+                         init_rates.data(), COLATE_DEFAULT_MAX_ITER, COLATE_DEFAULT_MIN_ITER,
+                         COLATE_DEFAULT_REL_TOL, COLATE_DEFAULT_RATE_FLOOR, rates.data(),
+                         iters.data(), ll.data(), flags.data());
+  }
   if (rc) {
     std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
     return 1;

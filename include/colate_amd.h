@@ -86,6 +86,19 @@ int colate_em_batch_device(int B, int E, int A, const double* age_grid, const do
                            double rate_floor, double* out_rates, int* out_iters,
                            double* out_loglik, int* out_flags, void* hip_stream);
 
+/* Host-pointer variant that shards the B replicates over several GPUs of the node from ONE
+ * process: contiguous, balanced ranges (replicate i of device d = global lo_d + i), one stream per
+ * device, all launches in flight together, results gathered in replicate order.  `devices` lists
+ * `num_devices` HIP ordinals (an ordinal may repeat: its shards then share that GPU).  The
+ * one-process-per-GPU form of the same sharding (torch.distributed + RCCL all-gather) is
+ * colate_amd/distributed.py; there is no exchange between shards inside the EM. */
+int colate_em_batch_sharded(int num_devices, const int* devices, int B, int E, int A,
+                            const double* age_grid, const double* cnt_shared,
+                            const double* cnt_notshared, const double* epochs,
+                            const double* init_rates, int max_iter, int min_iter, double rel_tol,
+                            double rate_floor, double* out_rates, int* out_iters, double* out_loglik,
+                            int* out_flags);
+
 /* One E-step = one pass of coal.cpp:3698-3733 for each of B replicates with the
  * rates given per replicate: rates[B][E] -> num_acc[B][E], den_acc[B][E]
  * (coal_rates_num / coal_rates_denom), loglik[B], flags[B]. */

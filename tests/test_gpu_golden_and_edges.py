@@ -207,3 +207,19 @@ def test_device_entry_points_with_torch(ca):
     for b, e in enumerate((ep_a, ep_b, ep_a, ep_b)):
         r0, it0, _, _ = ol.em_batch(grid, csh[b:b + 1], cns[b:b + 1], e)
         assert int(it[b]) == it0[0] and _rel(out[b].cpu().numpy(), r0[0]).max() < 1e-8
+
+
+def test_sharded_entry_point_matches_single_launch(ca):
+    """colate_em_batch_sharded (one process, several shards/streams; here all on GPU 0) returns the
+    replicates in order, bit-identical to one launch."""
+    from colate_amd import workloads
+
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins("3,7,0.2")
+    csh, cns = workloads.bootstrap_tables(grid, 11, nb=9, scale=1.0)
+    r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep)
+    for devs in ([0], [0, 0, 0], [0] * 16):
+        r, it, ll, fl = ca.em_batch_sharded(devs, grid, csh, cns, ep)
+        assert np.array_equal(r, r1) and np.array_equal(ll, ll1) and (it == it1).all() and (fl == fl1).all()
+    with pytest.raises(ca.ColateError):
+        ca.em_batch_sharded([99], grid, csh, cns, ep)
