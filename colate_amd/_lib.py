@@ -35,6 +35,8 @@ SIGNATURES = {
     "colate_em_batch_device": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p, c_int, c_int, c_int, c_double, c_double, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
+    "colate_em_batch_rows": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "colate_em_batch_sharded": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "colate_em_estep": (c_int, [c_int, c_int, c_int] + [c_void_p] * 9),

@@ -107,6 +107,23 @@ def em_batch(age_grid_, cnt_shared, cnt_notshared, epochs, init_rates=None, max_
     return rates, iters, ll, flags
 
 
+def em_batch_rows(age_grid_, cnt_shared, cnt_notshared, epochs_rows, init_rows=None, max_iter=DEFAULT_MAX_ITER,
+                  min_iter=DEFAULT_MIN_ITER, rel_tol=DEFAULT_REL_TOL, rate_floor=DEFAULT_RATE_FLOOR):
+    """colate_em_batch_rows: epochs[B][E] (and starting rates) per replicate -- batched all-pairs."""
+    g, sh, ns, ep = _f64(age_grid_), _f64(np.atleast_2d(cnt_shared)), _f64(np.atleast_2d(cnt_notshared)), _f64(epochs_rows)
+    B, A = sh.shape
+    E = ep.shape[1]
+    assert ep.shape == (B, E)
+    init = _f64(np.full((B, E), DEFAULT_INIT_RATE) if init_rows is None else init_rows)
+    rates = np.zeros((B, E))
+    iters = np.zeros(B, dtype=np.int32)
+    ll = np.zeros(B)
+    flags = np.zeros(B, dtype=np.int32)
+    check(lib.colate_em_batch_rows(B, E, A, _p(g), _p(sh), _p(ns), _p(ep), _p(init), max_iter, min_iter, rel_tol,
+                                   rate_floor, _p(rates), _p(iters), _p(ll), _p(flags)))
+    return rates, iters, ll, flags
+
+
 def em_batch_sharded(devices, age_grid_, cnt_shared, cnt_notshared, epochs, init_rates=None, max_iter=DEFAULT_MAX_ITER,
                      min_iter=DEFAULT_MIN_ITER, rel_tol=DEFAULT_REL_TOL, rate_floor=DEFAULT_RATE_FLOOR):
     """colate_em_batch_sharded: one process drives the GPUs listed in `devices` (ordinals may repeat)."""

@@ -203,6 +203,47 @@ int colate_em_batch(int B, int E, int A, const double* age_grid, const double* c
   return COLATE_OK;
 }
 
+int colate_em_batch_rows(int B, int E, int A, const double* age_grid, const double* cnt_shared,
+                         const double* cnt_notshared, const double* epochs, const double* init_rates,
+                         int max_iter, int min_iter, double rel_tol, double rate_floor,
+                         double* out_rates, int* out_iters, double* out_loglik, int* out_flags) {
+  if (int rc = check_sizes(B, E, A)) return rc;
+  if (!age_grid || !cnt_shared || !cnt_notshared || !epochs || !init_rates || !out_rates ||
+      !out_iters || !out_loglik || !out_flags)
+    return fail(COLATE_EINVAL, "NULL pointer argument");
+  for (int b = 0; b < B; b++)
+    if (int rc = check_grids(E, A, age_grid, epochs + (size_t)b * E)) return rc;
+  if (int rc = ensure_device()) return rc;
+  if (B == 0) return COLATE_OK;
+  const size_t nBA = (size_t)B * A, nBE = (size_t)B * E;
+  DevBuf d_grid, d_sh, d_ns, d_ep, d_init, d_rates, d_iters, d_ll, d_flags;
+  HIP_TRY(d_grid.alloc(A * sizeof(double)));
+  HIP_TRY(d_sh.alloc(nBA * sizeof(double)));
+  HIP_TRY(d_ns.alloc(nBA * sizeof(double)));
+  HIP_TRY(d_ep.alloc(nBE * sizeof(double)));
+  HIP_TRY(d_init.alloc(nBE * sizeof(double)));
+  HIP_TRY(d_rates.alloc(nBE * sizeof(double)));
+  HIP_TRY(d_iters.alloc(B * sizeof(int)));
+  HIP_TRY(d_ll.alloc(B * sizeof(double)));
+  HIP_TRY(d_flags.alloc(B * sizeof(int)));
+  HIP_TRY(hipMemcpy(d_grid.p, age_grid, A * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_sh.p, cnt_shared, nBA * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_ns.p, cnt_notshared, nBA * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_ep.p, epochs, nBE * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_init.p, init_rates, nBE * sizeof(double), hipMemcpyHostToDevice));
+  int rc = colate_em_batch_device(B, E, A, d_grid.as<double>(), d_sh.as<double>(),
+                                  d_ns.as<double>(), d_ep.as<double>(), 1, d_init.as<double>(), 1,
+                                  max_iter, min_iter, rel_tol, rate_floor, d_rates.as<double>(),
+                                  d_iters.as<int>(), d_ll.as<double>(), d_flags.as<int>(), nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out_rates, d_rates.p, nBE * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_iters, d_iters.p, B * sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_loglik, d_ll.p, B * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_flags, d_flags.p, B * sizeof(int), hipMemcpyDeviceToHost));
+  return COLATE_OK;
+}
+
 int colate_em_batch_sharded(int num_devices, const int* devices, int B, int E, int A,
                             const double* age_grid, const double* cnt_shared,
                             const double* cnt_notshared, const double* epochs,

@@ -50,7 +50,7 @@ const char* const kValueOptions[] = {
     "target_table", "target_bam", "reference_bam", "target_tmp", "reference_tmp", "target_age",
     "reference_age", "ref_genome", "anc_genome", "mask", "mask_cutoff", "chr", "bins",
     "lineage_bin", "outgroup_tmrca", "years_per_gen", "coal", "seed", "num_bootstraps", "filters",
-    "groups", "poplabels", "map", "input", "output", "device", "devices", "counts_out"};
+    "groups", "poplabels", "map", "input", "output", "device", "devices", "counts_out", "pairs"};
 const char* const kBoolOptions[] = {"help", "strandfilter", "counts_only"};
 
 bool parse_options(int argc, char** argv, Options& o, std::string& err) {
@@ -119,6 +119,9 @@ void print_help() {
             << "      --num_bootstraps arg   Optional: Number of bootstraps.\n"
             << "      --device arg           Optional (colate_amd): GPU ordinal, default 0.\n"
             << "      --devices arg          Optional (colate_amd): shard the bootstrap replicates over GPUs 0..N-1.\n"
+            << "      --pairs arg            Optional (colate_amd): file of `target_tmp reference_tmp output [target_age reference_age]`\n"
+            << "                             lines; all pairs share --mut/--chr/--bins/--num_bootstraps/--seed, each .mut is parsed\n"
+            << "                             once and all replicates of all pairs run in one GPU launch.\n"
             << "      --counts_out arg       Optional (colate_amd): write the bootstrap count tables (.colate_mat layout).\n"
             << "      --counts_only          Optional (colate_amd): stop after --counts_out (no GPU needed).\n"
             << "  -o, --output arg           Filename of output.\n"
@@ -290,7 +293,8 @@ int fill_tables_from_tmp(const std::vector<std::string>& chr_names,
                          const std::vector<std::string>& mut_files, const std::string& target_file,
                          const std::string& ref_file, const std::vector<std::string>& target_masks,
                          const std::vector<std::string>& ref_masks, double C, std::mt19937& rng,
-                         int num_bases_per_block, int A, BlockTables& tab) {
+                         int num_bases_per_block, int A, BlockTables& tab,
+                         std::map<std::string, std::vector<MutRow>>* mut_cache = nullptr) {
   const double age = 0, ref_age = 0;  // forced, coal.cpp:2074-2075
   std::uniform_real_distribution<double> dist_unif(0, 1);
   const float num_samples = 100;
@@ -310,11 +314,23 @@ int fill_tables_from_tmp(const std::vector<std::string>& chr_names,
     if (blk >= tab.sh.size()) tab.add_block(A);
   };
 
-  std::vector<MutRow> rows;
+  std::vector<MutRow> rows_local;
   std::string tar_mask, ref_mask, ancestral, derived;
   for (size_t chr = 0; chr < mut_files.size(); chr++) {
     std::cerr << "parsing CHR: " << chr + 1 << " / " << mut_files.size() << std::endl;
-    read_mut_file(mut_files[chr], rows);
+    // --pairs: every (target, reference) pair walks the same .mut rows; parse each file once
+    const std::vector<MutRow>* rows_p = &rows_local;
+    if (mut_cache) {
+      auto it = mut_cache->find(mut_files[chr]);
+      if (it == mut_cache->end()) {
+        read_mut_file(mut_files[chr], (*mut_cache)[mut_files[chr]]);
+        it = mut_cache->find(mut_files[chr]);
+      }
+      rows_p = &it->second;
+    } else {
+      read_mut_file(mut_files[chr], rows_local);
+    }
+    const std::vector<MutRow>& rows = *rows_p;
     if (has_tar_mask) read_fasta_mask(target_masks[chr], tar_mask);
     if (has_ref_mask) read_fasta_mask(ref_masks[chr], ref_mask);
     int current_block_base = 0;
@@ -645,6 +661,187 @@ int run_mut(const Options& opt) {
   return 0;
 }
 
+
+// ------------------------------------------------------------------ --pairs (batched all-pairs)
+// Not in the reference CLI (one run per pair there, re-parsing every .mut each time).  Every pair
+// is processed exactly as its own `--mode mut` run would be (RNG re-seeded from --seed, own block
+// tables, own epochs when a sample is ancient); the EM of ALL replicates of ALL pairs is one launch
+// per distinct epoch count.
+struct PairSpec {
+  std::string target, reference, output;
+  double target_age = 0, ref_age = 0;
+};
+
+void write_counts_file(const std::string& path, int B, int A, const std::vector<double>& grid,
+                       const double* csh, const double* cns) {
+  FILE* f = std::fopen(path.c_str(), "w");
+  if (!f) {
+    std::cerr << "Error: cannot write " << path << std::endl;
+    std::exit(1);
+  }
+  for (int b = 0; b < A; b++) std::fprintf(f, "%.17g ", grid[b]);
+  std::fprintf(f, "\n");
+  for (int i = 0; i < B; i++) {
+    for (int b = 0; b < A; b++) std::fprintf(f, "%.17g ", csh[(size_t)i * A + b]);
+    std::fprintf(f, "\n");
+    for (int b = 0; b < A; b++) std::fprintf(f, "%.17g ", cns[(size_t)i * A + b]);
+    std::fprintf(f, "\n");
+  }
+  std::fclose(f);
+}
+
+int run_mut_pairs(const Options& opt) {
+  if (!opt.has("mut") || !opt.has("bins")) {
+    std::cerr << "Error: --pairs needs --mut and --bins (and optionally --chr, --num_bootstraps, --seed)." << std::endl;
+    return 1;
+  }
+  std::vector<PairSpec> pairs;
+  {
+    std::ifstream is(opt.get("pairs"));
+    if (!is) {
+      std::cerr << "Error while opening file " << opt.get("pairs") << std::endl;
+      return 1;
+    }
+    std::string line;
+    while (std::getline(is, line)) {
+      std::istringstream ss(line);
+      PairSpec ps;
+      if (!(ss >> ps.target >> ps.reference >> ps.output)) continue;
+      std::string a1, a2;
+      if (ss >> a1) ps.target_age = std::stof(a1);
+      if (ss >> a2) ps.ref_age = std::stof(a2);
+      pairs.push_back(ps);
+    }
+  }
+  if (pairs.empty()) {
+    std::cerr << "Error: no pairs in " << opt.get("pairs") << std::endl;
+    return 1;
+  }
+  std::cerr << "---------------------------------------------------------" << std::endl;
+  std::cerr << "Calculating coalescence rates for " << pairs.size() << " pairs of (ancient) samples.." << std::endl;
+  double years_per_gen = 28.0;
+  if (opt.has("years_per_gen")) years_per_gen = std::stof(opt.get("years_per_gen"));
+  const double C = 10;
+  std::vector<double> age_grid(256);
+  const int A = colate_age_grid(age_grid.data(), 256);
+  age_grid.resize(A);
+  const int num_bases_per_block = 30e6;
+  int seed = std::time(0) + getpid();
+  if (opt.has("seed")) seed = std::stoi(opt.get("seed"));
+  int B = 1;
+  if (opt.has("num_bootstraps")) B = std::stoi(opt.get("num_bootstraps"));
+  if (B < 1) {
+    std::cerr << "Error: --num_bootstraps must be at least 1." << std::endl;
+    return 1;
+  }
+  std::vector<std::string> mut_files, tmask, rmask, names;
+  if (opt.has("chr")) {
+    GzText is_chr;
+    if (!is_chr.open(opt.get("chr"))) std::cerr << "Error while opening file " << opt.get("chr") << std::endl;
+    std::string line;
+    while (is_chr.getline(line)) {
+      names.push_back(line);
+      mut_files.push_back(opt.get("mut") + "_chr" + line + ".mut");
+    }
+  } else {
+    names.push_back("");
+    mut_files.push_back(opt.get("mut"));
+  }
+
+  const size_t P = pairs.size();
+  std::map<std::string, std::vector<MutRow>> mut_cache;
+  std::vector<std::vector<double>> csh(P), cns(P), epochs(P);
+  std::vector<int> ep_null(P, 0);
+  std::vector<double> age(P);
+  for (size_t p = 0; p < P; p++) {
+    std::cerr << "Pair " << p + 1 << " / " << P << ": " << pairs[p].target << " x " << pairs[p].reference << std::endl;
+    age[p] = std::max(pairs[p].target_age, pairs[p].ref_age) / years_per_gen;
+    std::mt19937 rng;
+    rng.seed(seed);  // as an independent run of this pair would
+    BlockTables tab;
+    const int nb = fill_tables_from_tmp(names, mut_files, pairs[p].target, pairs[p].reference, tmask, rmask, C, rng,
+                                        num_bases_per_block, A, tab, &mut_cache);
+    std::cerr << "Number of blocks: " << nb << std::endl;
+    if (nb < 1) {
+      std::cerr << "Error: no genome blocks were read." << std::endl;
+      return 1;
+    }
+    std::vector<double> fsh((size_t)nb * A), fns((size_t)nb * A), fshe((size_t)nb * A), fnse((size_t)nb * A);
+    for (int j = 0; j < nb; j++) {
+      std::copy(tab.sh[j].begin(), tab.sh[j].end(), fsh.begin() + (size_t)j * A);
+      std::copy(tab.ns[j].begin(), tab.ns[j].end(), fns.begin() + (size_t)j * A);
+      std::copy(tab.sh_emp[j].begin(), tab.sh_emp[j].end(), fshe.begin() + (size_t)j * A);
+      std::copy(tab.ns_emp[j].begin(), tab.ns_emp[j].end(), fnse.begin() + (size_t)j * A);
+    }
+    csh[p].assign((size_t)B * A, 0.0);
+    cns[p].assign((size_t)B * A, 0.0);
+    if (int rc = colate_bootstrap_counts(&rng, B, nb, A, age_grid.data(), age[p], fsh.data(), fns.data(), fshe.data(),
+                                         fnse.data(), csh[p].data(), cns[p].data())) {
+      std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
+      return 1;
+    }
+    if (opt.has("counts_only") || opt.has("counts_out"))
+      write_counts_file(pairs[p].output + ".counts", B, A, age_grid, csh[p].data(), cns[p].data());
+    epochs[p].resize(COLATE_MAX_EPOCHS);
+    const int E = colate_epochs_from_bins(opt.get("bins").c_str(), age[p], years_per_gen, epochs[p].data(),
+                                          COLATE_MAX_EPOCHS, &ep_null[p]);
+    if (E <= 0) {
+      std::cerr << colate_last_error() << std::endl;
+      return 1;
+    }
+    epochs[p].resize(E);
+  }
+  if (opt.has("counts_only")) return 0;
+
+  std::cerr << "Maximising likelihood using EM.. " << std::endl;
+  if (opt.has("device")) {
+    if (int rc = colate_set_device(std::stoi(opt.get("device")))) {
+      std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
+      return 1;
+    }
+  }
+  std::vector<bool> done(P, false);
+  for (size_t p0 = 0; p0 < P; p0++) {  // one launch per distinct number of epochs
+    if (done[p0]) continue;
+    const int E = (int)epochs[p0].size();
+    std::vector<size_t> grp;
+    for (size_t p = p0; p < P; p++)
+      if (!done[p] && (int)epochs[p].size() == E) grp.push_back(p);
+    const size_t R = grp.size() * (size_t)B;
+    std::vector<double> g_sh(R * A), g_ns(R * A), g_ep(R * E), g_init(R * E, COLATE_DEFAULT_INIT_RATE), g_rates(R * E), g_ll(R);
+    std::vector<int> g_it(R), g_fl(R);
+    for (size_t k = 0; k < grp.size(); k++) {
+      const size_t p = grp[k];
+      std::copy(csh[p].begin(), csh[p].end(), g_sh.begin() + k * B * A);
+      std::copy(cns[p].begin(), cns[p].end(), g_ns.begin() + k * B * A);
+      for (int i = 0; i < B; i++) std::copy(epochs[p].begin(), epochs[p].end(), g_ep.begin() + (k * B + i) * E);
+    }
+    if (int rc = colate_em_batch_rows((int)R, E, A, age_grid.data(), g_sh.data(), g_ns.data(), g_ep.data(), g_init.data(),
+                                      COLATE_DEFAULT_MAX_ITER, COLATE_DEFAULT_MIN_ITER, COLATE_DEFAULT_REL_TOL,
+                                      COLATE_DEFAULT_RATE_FLOOR, g_rates.data(), g_it.data(), g_ll.data(), g_fl.data())) {
+      std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
+      return 1;
+    }
+    for (size_t k = 0; k < grp.size(); k++) {
+      const size_t p = grp[k];
+      for (int i = 0; i < B; i++)
+        std::cerr << "Pair " << p + 1 << " Bootstrap " << i + 1 << ": Total iterations " << g_it[k * B + i] << std::endl;
+      if (colate_write_coal((pairs[p].output + ".coal").c_str(), B, E, epochs[p].data(), g_rates.data() + k * B * E,
+                            age[p] > 0.0 ? 1 : 0, ep_null[p])) {
+        std::cerr << "Error: " << colate_last_error() << std::endl;
+        return 1;
+      }
+      done[p] = true;
+    }
+  }
+  rusage usage;
+  getrusage(RUSAGE_SELF, &usage);
+  std::cerr << "CPU Time spent: " << usage.ru_utime.tv_sec << "." << std::setfill('0') << std::setw(6)
+            << usage.ru_utime.tv_usec << "s; Max Memory usage: " << usage.ru_maxrss / 1000.0 << "Mb." << std::endl;
+  std::cerr << "---------------------------------------------------------" << std::endl << std::endl;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int colate_mut_main(int argc, char** argv) {
@@ -667,6 +864,7 @@ extern "C" int colate_mut_main(int argc, char** argv) {
       return 0;
     }
     try {
+      if (opt.has("pairs")) return run_mut_pairs(opt);
       return run_mut(opt);
     } catch (const std::exception& e) {
       std::cerr << "Error: " << e.what() << std::endl;

@@ -86,6 +86,14 @@ int colate_em_batch_device(int B, int E, int A, const double* age_grid, const do
                            double rate_floor, double* out_rates, int* out_iters,
                            double* out_loglik, int* out_flags, void* hip_stream);
 
+/* Host-pointer variant with epochs[B][E] and init_rates[B][E] per replicate: one launch for many
+ * (target, reference) pairs whose epochs differ (an ancient sample inserts its age as an epoch,
+ * coal.cpp:3597-3624); all rows must have the same E.  Used by `Colate --pairs` (batched all-pairs). */
+int colate_em_batch_rows(int B, int E, int A, const double* age_grid, const double* cnt_shared,
+                         const double* cnt_notshared, const double* epochs, const double* init_rates,
+                         int max_iter, int min_iter, double rel_tol, double rate_floor,
+                         double* out_rates, int* out_iters, double* out_loglik, int* out_flags);
+
 /* Host-pointer variant that shards the B replicates over several GPUs of the node from ONE
  * process: contiguous, balanced ranges (replicate i of device d = global lo_d + i), one stream per
  * device, all launches in flight together, results gathered in replicate order.  `devices` lists

@@ -223,3 +223,20 @@ def test_sharded_entry_point_matches_single_launch(ca):
         assert np.array_equal(r, r1) and np.array_equal(ll, ll1) and (it == it1).all() and (fl == fl1).all()
     with pytest.raises(ca.ColateError):
         ca.em_batch_sharded([99], grid, csh, cns, ep)
+
+
+def test_pairs_mode_one_launch_equals_separate_runs(ca, tmp_path):
+    """Batched all-pairs front end: one process, one launch per distinct epoch count; every pair's
+    .coal is byte-identical to the .coal of that pair run on its own."""
+    gl.l3_stage("l3_ancient", str(tmp_path))
+    common = ["--mode", "mut", "--mut", "P", "--chr", "chr.txt", "--bins", "3,7,0.2", "--seed", "5", "--num_bootstraps", "2"]
+    specs = [("T.colate.in", "R.colate.in", "ab", "7000", "0"), ("R.colate.in", "T.colate.in", "ba", "0", "0"),
+             ("T.colate.in", "T.colate.in", "aa", "0", "0")]
+    (tmp_path / "pairs.txt").write_text("".join(" ".join(sp) + "\n" for sp in specs))
+    r = subprocess.run([CLI] + common + ["--pairs", "pairs.txt"], cwd=str(tmp_path), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    for tgt, ref, out, ta, ra in specs:
+        r = subprocess.run([CLI] + common + ["--target_tmp", tgt, "--reference_tmp", ref, "--target_age", ta,
+                                             "--reference_age", ra, "-o", out + "_single"], cwd=str(tmp_path), capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        assert (tmp_path / (out + ".coal")).read_text() == (tmp_path / (out + "_single.coal")).read_text()

@@ -164,3 +164,20 @@ def test_cli_option_errors(tmp_path):
     args = [("--num_bootstrap" if a == "--num_bootstraps" else a) for a in case["args"]]
     r = _run_cli(args + ["--counts_out", "c.txt", "--counts_only"], str(tmp_path))
     assert r.returncode == 0, r.stderr.decode()[-500:]
+
+
+def test_pairs_mode_counts_equal_separate_runs(tmp_path):
+    """`--pairs` (batched all-pairs, configs[4]): every pair's count tables are exactly what a run of
+    that pair alone produces (RNG re-seeded per pair; the .mut files are parsed once)."""
+    case = gl.l3_stage("l3_ancient", str(tmp_path))
+    common = ["--mode", "mut", "--mut", "P", "--chr", "chr.txt", "--bins", "3,7,0.2", "--seed", "5", "--num_bootstraps", "2"]
+    specs = [("T.colate.in", "R.colate.in", "ab", "7000", "0"), ("R.colate.in", "T.colate.in", "ba", "0", "0")]
+    (tmp_path / "pairs.txt").write_text("".join(" ".join(sp) + "\n" for sp in specs))
+    r = _run_cli(common + ["--pairs", "pairs.txt", "--counts_only"], str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    assert r.stderr.decode().count("parsing CHR: 1 / 3") == 2
+    for tgt, ref, out, ta, ra in specs:
+        r = _run_cli(common + ["--target_tmp", tgt, "--reference_tmp", ref, "--target_age", ta, "--reference_age", ra,
+                               "-o", out + "_single", "--counts_out", out + "_single.counts", "--counts_only"], str(tmp_path))
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        assert (tmp_path / (out + ".counts")).read_text() == (tmp_path / (out + "_single.counts")).read_text()
