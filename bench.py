@@ -36,7 +36,7 @@ B_PER_GPU = 100
 CPU_SAMPLE = 64  # replicates timed on the host (about 10 s on one core)
 
 
-def cpu_baseline(grid, csh, cns, epochs, gpu_rates, gpu_iters):
+def cpu_baseline(grid, csh, cns, epochs, gpu_rates, gpu_iters, bins=BINS):
     """Time the CPU path on `CPU_SAMPLE` of the benchmark's replicates, one core."""
     S = min(CPU_SAMPLE, csh.shape[0])
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "Colate_ref")
@@ -49,7 +49,7 @@ def cpu_baseline(grid, csh, cns, epochs, gpu_rates, gpu_iters):
                 for b in range(S):
                     f.write(" ".join("%.17g" % x for x in csh[b]) + "\n")
                     f.write(" ".join("%.17g" % x for x in cns[b]) + "\n")
-            cmd = [ref_bin, "--mode", "mut", "--mut", "dummy", "--bins", BINS, "--num_bootstraps", str(S), "-o", "OUT"]
+            cmd = [ref_bin, "--mode", "mut", "--mut", "dummy", "--bins", bins, "--num_bootstraps", str(S), "-o", "OUT"]
             t0 = time.perf_counter()
             r = subprocess.run(cmd, cwd=d, capture_output=True, text=True)
             dt = time.perf_counter() - t0
@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicates", type=int, default=B_PER_GPU, help="bootstrap replicates per GPU")
+    ap.add_argument("--bins", default=BINS, help="epoch grid (default: the BASELINE config; 2,7.95,0.05 = 122 epochs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive (host-pointer ABI) timing")
     args = ap.parse_args()
@@ -119,7 +120,8 @@ def main():
 
     B = args.replicates
     grid = colate_amd.age_grid()
-    epochs, _ = colate_amd.epochs_from_bins(BINS)
+    bins = args.bins
+    epochs, _ = colate_amd.epochs_from_bins(bins)
     E, A = epochs.size, grid.size
     # every rank bootstraps its own B replicates of the same genome (weak scaling)
     csh, cns = workloads.bootstrap_tables(grid, B, nb=115, scale=11.0, seed=12345 + 1000 * rank)
@@ -196,7 +198,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"whole-genome-like LBK-vs-Loschbour-shaped count tables (nb=115 blocks), "
-                            f"num_bootstrap={B} per GPU, --bins {BINS} (E={E} epochs), A={A} age bins, "
+                            f"num_bootstrap={B} per GPU, --bins {bins} (E={E} epochs), A={A} age bins, "
                             f"EM to the reference stop rule (min 1001 iterations)",
                 "replicates_per_gpu": B, "epochs": E, "age_bins": A,
                 "parallelism": f"replicates sharded over {world} GPU(s), one RCCL all-gather of rates per step",
@@ -227,7 +229,7 @@ def main():
             out["host_path"] = {"value": 5 * B / (time.perf_counter() - t1), "unit": "replicates/s",
                                 "note": "colate_em_batch with host buffers, PCIe and allocation inclusive"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(grid, csh, cns, epochs, rates, iters)
+            out["cpu_baseline"] = cpu_baseline(grid, csh, cns, epochs, rates, iters, bins)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -347,15 +347,19 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
 #pragma unroll
     for (int c = 0; c < NCH; c++) q_e[c] = p_e[c] = beta_e[c] = S_e[c] = omS_e[c] = cs_e[c] = csn_e[c] = 0.0;
     if (leader) {
-      // cs_e = sum_{j<e} lambda_j dt_j (coal_EM.cpp:100-103), as a wave scan (both roles need its bits)
-      double carry = 0.0;
+      double x_e[NCH];
 #pragma unroll
-      for (int c = 0; c < NCH; c++) {
-        const double x = lam_e[c] * dt_e[c];
-        const double incl = wave_prefix_sum(x, erows);
-        cs_e[c] = carry + dpp_d<WAVE_SHR1, 0xf, true>(0.0, incl);
-        csn_e[c] = cs_e[c] + x;
-        carry = carry + readlane_d(incl, 63);
+      for (int c = 0; c < NCH; c++) x_e[c] = lam_e[c] * dt_e[c];
+      if (role == 0) {
+        // cs_e = sum_{j<e} lambda_j dt_j (coal_EM.cpp:100-103), as a wave scan
+        double carry = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+          const double incl = wave_prefix_sum(x_e[c], erows);
+          cs_e[c] = carry + dpp_d<WAVE_SHR1, 0xf, true>(0.0, incl);
+          csn_e[c] = cs_e[c] + x_e[c];
+          carry = carry + readlane_d(incl, 63);
+        }
       }
       COLATE_STAMP(8)
       if (role == 0) {
@@ -363,9 +367,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
         for (int c = 0; c < NCH; c++) {
           const int e = c * kWave + lane;
           S_e[c] = em::em_exp_om(-cs_e[c], &omS_e[c]);  // omS = 1 - S_e = sum_{j<e} exp(A_ep[j])
-          const double inv = 1.0 / lam_e[c];
           if (ep_on[c]) {
-            s_ep[G_XA * EPAD + e] = (t_e[c] + inv) / inv;  // coal_EM.cpp:204 (kept as a division: X below cancels)
             s_ep[G_CS * EPAD + e] = cs_e[c];
             s_ep[G_S * EPAD + e] = S_e[c];
             s_ep[G_PW * EPAD + e] = omS_e[c];
@@ -378,7 +380,9 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
           const double inv = 1.0 / lam_e[c];
           const bool valid = vstat[c] && (lam_e[c] > 0);
           if (e < E - 1) {
-            q_e[c] = em::em_exp(-csn_e[c] + cs_e[c]);  // exp(-cumsum[i+1] + cumsum[i]), coal_EM.cpp:120
+            // exp(-cumsum[i+1] + cumsum[i]) of coal_EM.cpp:120, taken as exp(-lambda_e dt_e): the two arguments
+            // differ by the rounding of cumsum (<= ulp(cs)/2), and role B then needs no scan at all
+            q_e[c] = em::em_exp(-x_e[c]);
             if (valid) {
               p_e[c] = 1.0 - q_e[c];                                  // exp(A_ep + cs), coal_EM.cpp:119
               beta_e[c] = (t_e[c] + inv) - (tn_e[c] + inv) * q_e[c];  // exp(B_ep + cs), coal_EM.cpp:120
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
           if (ep_on[c]) {
             s_ep[G_LAM * EPAD + e] = lam_e[c];
             s_ep[G_INV * EPAD + e] = inv;
+            s_ep[G_XA * EPAD + e] = (t_e[c] + inv) / inv;  // coal_EM.cpp:204 (kept as a division: X below cancels)
             s_ep[G_P * EPAD + e] = p_e[c];
             s_ep[G_BETA * EPAD + e] = beta_e[c];
           }
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
             double Gn = 1.0;  // mass still to coalesce after t_{e+1}, relative to survival there
             if (!absorbing) {
               COLATE_COLD();
-              Gn = 1.0 - em::em_exp(-s_ep[G_CS * EPAD + E - 1] + csn_e[c]);
+              Gn = 1.0 - em::em_exp(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + e + 1]);
             }
             // later not-shared bins contribute dt_e each, earlier ones their tail mass
             double dns = dt_e[c] * Cn[c] + ((beta_e[c] - t_e[c] * p_e[c]) * T[c] + dt_e[c] * Gn * (q_e[c] * T[c]));

@@ -240,3 +240,45 @@ def test_pairs_mode_one_launch_equals_separate_runs(ca, tmp_path):
                                              "--reference_age", ra, "-o", out + "_single"], cwd=str(tmp_path), capture_output=True)
         assert r.returncode == 0, r.stderr.decode()[-800:]
         assert (tmp_path / (out + ".coal")).read_text() == (tmp_path / (out + "_single.coal")).read_text()
+
+
+@pytest.mark.parametrize("A", [1, 2, 64, 65, 130, 256])
+def test_custom_age_grids(ca, A):
+    """The ABI takes any non-decreasing age grid up to 256 bins (the reference reads its grid from
+    .colate_mat, coal.cpp:3481-3483): 1..4 bin groups per role, padding lanes, ties on epoch starts."""
+    rng = np.random.default_rng(A)
+    ep, _ = ol.epochs_from_bins("3,6.5,0.5")
+    grid = np.sort(np.exp(rng.uniform(np.log(2.0), np.log(4e5), A)))
+    if A >= 64:
+        grid[5] = ep[3]   # an age exactly on an epoch start belongs to the epoch that starts there
+        grid[6] = ep[3]
+        grid = np.sort(grid)
+    csh = rng.uniform(0, 30, (3, A)) * (rng.uniform(size=(3, A)) < 0.7) * (1 - np.exp(-grid / 9000.0))
+    cns = rng.uniform(0, 60, (3, A)) * (rng.uniform(size=(3, A)) < 0.7)
+    r, it, ll, fl = ca.em_batch(grid, csh, cns, ep, max_iter=1300)
+    r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep, max_iter=1300)
+    ok = (fl0 & 3) == 0  # (the cap of 1300 iterations may be hit: then both stop there, flagged alike)
+    assert ok.any() and (fl[ok] == fl0[ok]).all()
+    assert (it[ok] == it0[ok]).all() and np.allclose(ll[ok], ll0[ok], rtol=1e-11, atol=1e-13)
+    m = ol.stable_mask(grid, csh, cns, ep, r0, max_iter=1300)
+    assert _rel(r, r0)[m & ok[:, None]].max() < RATE_RTOL
+
+
+def test_flags(ca):
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins("3,7,0.2")
+    from colate_amd import workloads
+
+    csh, cns = workloads.bootstrap_tables(grid, 2, nb=9, scale=1.0)
+    # iteration cap reached before the stop rule can fire
+    r, it, ll, fl = ca.em_batch(grid, csh, cns, ep, max_iter=50)
+    assert (it == 50).all() and (fl == ca.FLAG_MAXITER).all()
+    r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep, max_iter=50)
+    assert _rel(r, r0).max() < 1e-9 and np.allclose(ll, ll0, rtol=1e-12)
+    # a not-shared count inside the last epoch with a zero last rate: the reference asserts (coal_EM.cpp:351)
+    cns2 = cns.copy()
+    cns2[:, 182] = 5.0
+    init = np.full(ep.size, 1.0 / 20000.0)
+    init[-1] = 0.0
+    num, den, ll, fl = ca.em_estep(grid, csh, cns2, ep, np.tile(init, (2, 1)))
+    assert (fl & ca.FLAG_NAN).all()
