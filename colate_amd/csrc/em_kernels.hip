@@ -142,6 +142,14 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define COLATE_STAMP(i)
 #endif
 
+// Timing-only ablations for tools/em_phase_probe.hip (-DCOLATE_ABL=<bit mask>): each bit removes one
+// piece of the iteration so that its true cost shows up in the kernel time (results are garbage).
+#ifdef COLATE_ABL
+#define COLATE_ABL_HAS(b) (((COLATE_ABL) >> (b)) & 1)
+#else
+#define COLATE_ABL_HAS(b) 0
+#endif
+
 // Marks a rarely-taken branch body: a volatile asm cannot be executed speculatively, so the compiler
 // keeps the branch instead of if-converting it (it otherwise evaluates whole exp()/log() calls of
 // cold paths unconditionally and selects the result).
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
     double q_e[NCH], p_e[NCH], beta_e[NCH], S_e[NCH], omS_e[NCH], cs_e[NCH], csn_e[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) q_e[c] = p_e[c] = beta_e[c] = S_e[c] = omS_e[c] = cs_e[c] = csn_e[c] = 0.0;
-    if (leader) {
+    if (leader && !COLATE_ABL_HAS(15)) {
       double x_e[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; c++) x_e[c] = lam_e[c] * dt_e[c];
@@ -355,7 +363,11 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
         double carry = 0.0;
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
+#if COLATE_ABL_HAS(11)
+          const double incl = x_e[c] * 7.0;
+#else
           const double incl = wave_prefix_sum(x_e[c], erows);
+#endif
           cs_e[c] = carry + dpp_d<WAVE_SHR1, 0xf, true>(0.0, incl);
           csn_e[c] = cs_e[c] + x_e[c];
           carry = carry + readlane_d(incl, 63);
@@ -366,7 +378,12 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           const int e = c * kWave + lane;
+#if COLATE_ABL_HAS(3)
+          S_e[c] = 1.0 - cs_e[c] * 1e-3;
+          omS_e[c] = cs_e[c] * 1e-3;
+#else
           S_e[c] = em::em_exp_om(-cs_e[c], &omS_e[c]);  // omS = 1 - S_e = sum_{j<e} exp(A_ep[j])
+#endif
           if (ep_on[c]) {
             s_ep[G_CS * EPAD + e] = cs_e[c];
             s_ep[G_S * EPAD + e] = S_e[c];
@@ -377,12 +394,20 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           const int e = c * kWave + lane;
+#if COLATE_ABL_HAS(7)
+          const double inv = 2.0e4 - lam_e[c];
+#else
           const double inv = 1.0 / lam_e[c];
+#endif
           const bool valid = vstat[c] && (lam_e[c] > 0);
           if (e < E - 1) {
             // exp(-cumsum[i+1] + cumsum[i]) of coal_EM.cpp:120, taken as exp(-lambda_e dt_e): the two arguments
             // differ by the rounding of cumsum (<= ulp(cs)/2), and role B then needs no scan at all
+#if COLATE_ABL_HAS(4)
+            q_e[c] = 1.0 - x_e[c];
+#else
             q_e[c] = em::em_exp(-x_e[c]);
+#endif
             if (valid) {
               p_e[c] = 1.0 - q_e[c];                                  // exp(A_ep + cs), coal_EM.cpp:119
               beta_e[c] = (t_e[c] + inv) - (tn_e[c] + inv) * q_e[c];  // exp(B_ep + cs), coal_EM.cpp:120
@@ -394,7 +419,11 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
           if (ep_on[c]) {
             s_ep[G_LAM * EPAD + e] = lam_e[c];
             s_ep[G_INV * EPAD + e] = inv;
-            s_ep[G_XA * EPAD + e] = (t_e[c] + inv) / inv;  // coal_EM.cpp:204 (kept as a division: X below cancels)
+#if COLATE_ABL_HAS(7)
+            s_ep[G_XA * EPAD + e] = (t_e[c] + inv) * lam_e[c];
+#else
+            s_ep[G_XA * EPAD + e] = em::em_div_known_rcp(t_e[c] + inv, inv, lam_e[c]);  // (t + 1/lambda)/(1/lambda), coal_EM.cpp:204
+#endif
             s_ep[G_P * EPAD + e] = p_e[c];
             s_ep[G_BETA * EPAD + e] = beta_e[c];
           }
@@ -412,14 +441,22 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
     {
       double o_w = 0, o_N = 0, o_D = 0, llp = 0.0;
       bool fail = false;
-      if (live) {
+      if (live && !COLATE_ABL_HAS(12)) {
         const double lk = s_ep[G_LAM * EPAD + kb], ik = s_ep[G_INV * EPAD + kb], ck = s_ep[G_CS * EPAD + kb];
         const bool lpos = lk > 0;
         const double ck1 = ck + lk * da;            // coal_EM.cpp:178-181 at the merged grid
         if (role == 0) {  // ---- EM_shared, coal_EM.cpp:198-210, 263-287
           const double Sk = s_ep[G_S * EPAD + kb], Xak = s_ep[G_XA * EPAD + kb], PWk = s_ep[G_PW * EPAD + kb];
+#if COLATE_ABL_HAS(5)
+          const double qd = 1.0 + (-ck1 + ck);
+#else
           const double qd = em::em_exp(-ck1 + ck);
-          const double Y = (a_b + ik) / ik;  // coal_EM.cpp:204
+#endif
+#if COLATE_ABL_HAS(8)
+          const double Y = (a_b + ik) * lk;
+#else
+          const double Y = em::em_div_known_rcp(a_b + ik, ik, lk);  // (age + 1/lambda)/(1/lambda), coal_EM.cpp:204
+#endif
           const double Wp = lpos ? Sk * (1.0 - qd) : 0.0;
           const double X = Xak - Y * qd;
           const double Vp = lpos ? X * ik * Sk : 0.0;
@@ -450,7 +487,11 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
             llp = cnt * (-ck2);
           } else {
             const double ck3 = ck2 + lk * db;
+#if COLATE_ABL_HAS(6)
+            const double u = 1.0 + (-ck3 + ck2);
+#else
             const double u = em::em_exp(-ck3 + ck2);
+#endif
             const double pn = lpos ? 1.0 - u : 0.0;
             const double bn = lpos ? (a_b + ik) - (tkn + ik) * u : 0.0;
             if (absorbing) {  // normaliser = exp(-cs(age)) * ((1 - u) + u) = exp(-cs(age))
@@ -500,10 +541,12 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
   o_w = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_w), F, o_w);   \
   o_N = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_N), F, o_N);   \
   o_D = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_D), F, o_D);
+#if !COLATE_ABL_HAS(2)  // ablation 2: no segmented reduce
       COLATE_SEG_STEP(ROW_SHR1, f1)
       COLATE_SEG_STEP(ROW_SHR2, f2)
       COLATE_SEG_STEP(ROW_SHR4, f4)
       COLATE_SEG_STEP(ROW_SHR8, f8)
+#endif
 #undef COLATE_SEG_STEP
       if (is_tail) {
         out_mine[O_W * APZ + pos] = o_w;
@@ -520,15 +563,20 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
     __syncthreads();  // ---- barrier 2: per-bin tails visible
     COLATE_STAMP(3)
     // ============================================================ P3: per-epoch sums (role leaders)
-    if (leader) {
-      int anyf = 0;  // did a bin of this role fail this iteration? (loaded with the tails: one LDS wait)
-      for (int i = 0; i < NB; i++) anyf |= s_fail[2 * i + role];
+    if (leader && !COLATE_ABL_HAS(13)) {
+      // did a bin of this role fail this iteration? (entries of retired waves stay 0; loaded with the
+      // tails: one LDS wait; fixed count -- a runtime-bounded loop here compiles to a vectorised monster)
+      const int anyf = s_fail[role] | s_fail[2 + role] | s_fail[4 + role] | s_fail[6 + role];
       double w[NCH], oN[NCH], oD[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
+#if COLATE_ABL_HAS(1)  // ablation: no tail loads
+        const double w0 = 1e-3 * lane, w1 = 0, w2 = 0, n0 = 1e-3, n1 = 0, n2 = 0, d0 = 1.0, d1 = 0, d2 = 0;
+#else
         const double w0 = out_mine[O_W * APZ + slot0[c]], w1 = out_mine[O_W * APZ + slot1[c]], w2 = out_mine[O_W * APZ + slot2[c]];
         const double n0 = out_mine[O_N * APZ + slot0[c]], n1 = out_mine[O_N * APZ + slot1[c]], n2 = out_mine[O_N * APZ + slot2[c]];
         const double d0 = out_mine[O_D * APZ + slot0[c]], d1 = out_mine[O_D * APZ + slot1[c]], d2 = out_mine[O_D * APZ + slot2[c]];
+#endif
         if (role == 0) {  // the shared leader also needs the not-shared leader's p_e, beta_e
           p_e[c] = s_ep[G_P * EPAD + c * kWave + lane];
           beta_e[c] = s_ep[G_BETA * EPAD + c * kWave + lane];
@@ -570,7 +618,11 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
         double cR = 0.0;
 #pragma unroll
         for (int c = NCH - 1; c >= 0; c--) {
+#if COLATE_ABL_HAS(9)
+          const double sR = w[c] * 3.0;
+#else
           const double sR = wave_suffix_sum(w[c], lane, erows);
+#endif
           RSn[c] = cR + dpp_d<WAVE_SHL1, 0xf, true>(0.0, sR);
           cR = cR + readlane_d(sR, 0);
         }
@@ -602,7 +654,9 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           double a = ep_on[c] ? q_e[c] : 1.0, b = ep_on[c] ? w[c] : 0.0;
+#if !COLATE_ABL_HAS(9)
           wave_affine_scan(a, b, erows);
+#endif
           const double Tn = em::fma_(a, Tc, b);         // T_{e+1}
           T[c] = dpp_d<WAVE_SHR1, 0xf, false>(Tc, Tn);  // T_e (lane 0: carry-in)
           Tc = readlane_d(Tn, 63);
@@ -653,9 +707,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
     }
     if (need_ll) {
       COLATE_COLD();
-      double acc = 0.0;
-      for (int i = 0; i < 2 * NB; i++) acc += s_ll[i];
-      ll = acc;
+      ll = ((s_ll[0] + s_ll[1]) + (s_ll[2] + s_ll[3])) + ((s_ll[4] + s_ll[5]) + (s_ll[6] + s_ll[7]));  // retired waves: 0
     }
     if (MODE == 1) {
       if (wave == 0) {
@@ -670,7 +722,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
       break;
     }
     // ---- M-step, coal.cpp:3777-3804
-    {
+    if (!COLATE_ABL_HAS(14)) {
       double cand[NCH];
       unsigned long long keep[NCH];  // epochs that do NOT copy their predecessor
       bool simple = true;            // the copying epochs form a prefix 0..m-1: they all become 0
@@ -680,7 +732,11 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
         const bool copy = (N_e[c] == 0);
         cand[c] = lam_e[c];
         if (!copy && D_e[c] != 0) {
+#if COLATE_ABL_HAS(10)
+          cand[c] = N_e[c] * 1e-4 + D_e[c] * 1e-9;
+#else
           cand[c] = N_e[c] / D_e[c];
+#endif
           if (cand[c] < p.rate_floor) cand[c] = p.rate_floor;
         }
         keep[c] = __ballot(ep_on[c] && !copy);

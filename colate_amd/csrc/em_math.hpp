@@ -100,6 +100,19 @@ EM_HD double em_rcp(double x) {
 #endif
 }
 
+// n / d where a reciprocal y of d is already known to ~1 ulp -- here d = fl(1/lambda), y = lambda.
+// Quotient estimate + two Markstein corrections with the exact residual: equal to the IEEE
+// (correctly rounded) quotient in every one of 2e7 random trials of the shapes the kernel uses
+// (tests/test_em_math.py), at 5 instructions instead of the ~14 of a full division.
+EM_HD double em_div_known_rcp(double n, double d, double y) {
+  double q = n * y;
+  double r = fma_(-q, d, n);
+  q = fma_(r, y, q);
+  r = fma_(-q, d, n);
+  q = fma_(r, y, q);
+  return q;
+}
+
 // log(x) for finite x > 0 (normal or subnormal); <= ~1 ulp.  Only feeds the
 // log-likelihood (stop rule and reporting), where nothing amplifies its error.
 // log(0) = -inf, log(negative) = NaN as in libm.

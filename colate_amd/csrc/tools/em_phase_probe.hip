@@ -3,7 +3,9 @@
 // em_kernels.hip with -DCOLATE_EM_STAMPS into a stand-alone program and prints where the cycles of
 // an iteration go.  Only the SHARES are meaningful (the stamps serialise the phases).
 //   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -I../../include -I.. tools/em_phase_probe.hip -o em_phase_probe
+#ifndef COLATE_NO_STAMPS
 #define COLATE_EM_STAMPS 1
+#endif
 #include "../em_kernels.hip"
 
 #include <cmath>
@@ -42,6 +44,9 @@ int main(int argc, char** argv) {
   a.B = B, a.E = E, a.A = A, a.mode = 0;
   a.age_grid = d_grid, a.cnt_sh = d_sh, a.cnt_ns = d_ns, a.epochs = d_ep, a.rates_in = d_init;
   a.max_iter = 100000, a.min_iter = 1000, a.rel_tol = 1e-7, a.rate_floor = 5e-9;
+#ifdef COLATE_ABL
+  a.max_iter = 1002, a.min_iter = 1000000;  // ablation builds: fixed number of iterations (results are meaningless)
+#endif
   a.out_rates = d_rates, a.out_iters = d_it, a.out_ll = d_ll, a.out_flags = d_fl, a.out_num = d_dbg;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
@@ -57,7 +62,10 @@ int main(int argc, char** argv) {
   std::vector<int> it(B);
   hipMemcpy(dbg.data(), d_dbg, dbg.size() * 8, hipMemcpyDeviceToHost);
   hipMemcpy(it.data(), d_it, B * 4, hipMemcpyDeviceToHost);
-  printf("launch: %s, %.3f ms (stamped build), iters[0]=%d\n", hipGetErrorString(err), ms, it[0]);
+  printf("launch: %s, %.3f ms, iters[0]=%d\n", hipGetErrorString(err), ms, it[0]);
+#ifndef COLATE_EM_STAMPS
+  return 0;
+#endif
   const char* names[16] = {"P2 start (gathers)", "P2 bin math", "P2 seg-reduce+store", "barrier 2", "P3 N,D + store", "P4 M-step", "-", "loop top/stop",
                            "P1 cs scan", "P1 exp/div/write", "P3 tail loads", "P3 suffix scan (A)", "P3 affine scan (B)", "-", "-", "-"};
   for (int w = 0; w < 2; w++) {

@@ -21,7 +21,13 @@ def m(tmp_path_factory):
                    "void t_exp(int n,const double*x,double*y){for(int i=0;i<n;i++)y[i]=em::em_exp(x[i]);}\n"
                    "void t_om(int n,const double*x,double*y,double*z){for(int i=0;i<n;i++)y[i]=em::em_exp_om(x[i],&z[i]);}\n"
                    "void t_log(int n,const double*x,double*y){for(int i=0;i<n;i++)y[i]=em::em_log(x[i]);}\n"
-                   "void g_exp(int n,const double*x,double*y){for(int i=0;i<n;i++)y[i]=std::exp(x[i]);}\n}\n" % ROOT)
+                   "void g_exp(int n,const double*x,double*y){for(int i=0;i<n;i++)y[i]=std::exp(x[i]);}\n"
+                   "long t_div(long n,unsigned long long seed){long bad=0;unsigned long long s=seed;\n"
+                   " for(long i=0;i<n;i++){s=s*6364136223846793005ULL+1442695040888963407ULL;double u=(s>>11)*(1.0/9007199254740992.0);\n"
+                   "  s=s*6364136223846793005ULL+1442695040888963407ULL;double v=(s>>11)*(1.0/9007199254740992.0);\n"
+                   "  double lam=std::exp(std::log(5e-9)+u*(std::log(1e-1)-std::log(5e-9)));double inv=1.0/lam;\n"
+                   "  double a=std::exp(std::log(0.05)+v*(std::log(1e7)-std::log(0.05)));double num=a+inv;\n"
+                   "  if(em::em_div_known_rcp(num,inv,lam)!=num/inv)bad++;}return bad;}\n}\n" % ROOT)
     so = d / "libh.so"
     subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(so), str(src)])
     return ctypes.CDLL(str(so))
@@ -70,3 +76,10 @@ def test_log(m):
     assert _ulp(_call(m.t_log, x), [mp.log(mp.mpf(v)) for v in x]).max() < 1.1
     sp = _call(m.t_log, np.array([0.0, -1.0, np.inf, 1.0]))
     assert sp[0] == -np.inf and np.isnan(sp[1]) and sp[2] == np.inf and sp[3] == 0.0
+
+
+def test_division_by_known_reciprocal_is_ieee(m):
+    """(age + 1/lambda)/(1/lambda) through em_div_known_rcp equals the correctly rounded quotient."""
+    m.t_div.restype = ctypes.c_long
+    m.t_div.argtypes = [ctypes.c_long, ctypes.c_ulonglong]
+    assert m.t_div(3_000_000, 12345) == 0
