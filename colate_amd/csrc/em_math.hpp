@@ -33,13 +33,22 @@ EM_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c);
 // instructions run by one wave per SIMD, so depth is what costs).
 struct ExpParts {
   double y, k, rh, tp;
+  int ki;
 };
+EM_HD int em_lo32(double v) {
+  long long b;
+  __builtin_memcpy(&b, &v, 8);
+  return (int)b;
+}
 EM_HD ExpParts em_exp_parts(double xc) {
   const double LOG2E = 0x1.71547652b82fep+0;
   const double LN2_HI = 0x1.62e42fefa3800p-1;   // 42 significant bits: k*LN2_HI is exact
   const double LN2_LO = 0x1.ef35793c76730p-45;  // ln2 - LN2_HI
+  const double SHIFT = 0x1.8p52;                // adding 1.5*2^52 rounds to an integer in the low mantissa bits
   ExpParts o;
-  o.k = __builtin_rint(xc * LOG2E);
+  const double kd = fma_(xc, LOG2E, SHIFT);  // k = nearest integer to x*log2(e) (|x| <= 1100)
+  o.ki = em_lo32(kd);                        // ... as an int, without a convert
+  o.k = kd - SHIFT;                          // ... and as a double (exact)
   const double rh = fma_(-o.k, LN2_HI, xc);  // exact
   const double rl = -o.k * LN2_LO;           // |rl| < 1e-10
   // exp(rh) = 1 + rh + rh^2 * (1/2 + rh * P(rh)),  P = 1/3! + rh/4! + ... + rh^11/14!
@@ -66,23 +75,22 @@ EM_HD ExpParts em_exp_parts(double xc) {
   return o;
 }
 
-// exp(x), |error| <= ~0.52 ulp.  x may be any finite value or -inf; large
-// negative arguments underflow gradually to 0 through ldexp.
+// exp(x) for x <= 709, |error| <= ~0.52 ulp.  x may be any value down to -inf; large negative
+// arguments underflow gradually to 0 through ldexp.  A NaN argument is NOT propagated (fmax drops it:
+// the result is exp(-1100) = 0); the kernel's arguments are sums of finite products.
 EM_HD double em_exp(double x) {
-  const double xc = x > -1100.0 ? x : -1100.0;  // keeps k in range; exp(-1100) == 0 anyway
+  const double xc = __builtin_fmax(x, -1100.0);  // keeps k in range; exp(-1100) == 0 anyway
   const ExpParts o = em_exp_parts(xc);
-  const double y = __builtin_ldexp(o.y, (int)o.k);
-  return (x != x) ? x : y;  // NaN in -> NaN out (the max() above would have dropped it)
+  return __builtin_ldexp(o.y, o.ki);
 }
 
 // exp(x) and 1 - exp(x) for x <= 0, the latter without cancellation near 0 (|error| <= ~1 ulp).
 EM_HD double em_exp_om(double x, double* one_minus) {
-  const double xc = x > -1100.0 ? x : -1100.0;
+  const double xc = __builtin_fmax(x, -1100.0);
   const ExpParts o = em_exp_parts(xc);
-  const double y = __builtin_ldexp(o.y, (int)o.k);
-  const double om = (o.k == 0.0) ? -(o.rh + o.tp) : 1.0 - y;
-  *one_minus = (x != x) ? x : om;
-  return (x != x) ? x : y;
+  const double y = __builtin_ldexp(o.y, o.ki);
+  *one_minus = (o.ki == 0) ? -(o.rh + o.tp) : 1.0 - y;
+  return y;
 }
 
 // 1/x for finite x > 0 within ~1 ulp (not correctly rounded): hardware seed + two Newton steps.
