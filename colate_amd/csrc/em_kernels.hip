@@ -465,7 +465,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
             const double r = em::em_rcp(Sig);
             const double nk = Wp * r;
             double dk = Vp * r + (-tk * nk);
-            if (dk < 0.0) dk = 0.0;
+            dk = __builtin_fmax(dk, 0.0);
             o_w = cnt * r;
             o_N = cnt * nk;
             o_D = cnt * dk;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
           if (last_bin) {  // bin beyond the start of the last epoch, coal_EM.cpp:350-357
             if (!lpos) my_flags |= COLATE_FLAG_NAN;  // reference: assert(coal_rate_e > 0)
             double dk = (a_b + ik) - tk;
-            if (dk < 0.0) dk = 0.0;
+            dk = __builtin_fmax(dk, 0.0);
             o_N = cnt;
             o_D = cnt * dk;
             llp = cnt * (-ck2);
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
             const double bn = lpos ? (a_b + ik) - (tkn + ik) * u : 0.0;
             if (absorbing) {  // normaliser = exp(-cs(age)) * ((1 - u) + u) = exp(-cs(age))
               double dk = bn + (-tk * pn + dtk * (1.0 - pn));
-              if (dk < 0.0) dk = 0.0;
+              dk = __builtin_fmax(dk, 0.0);
               o_w = cnt * u;
               o_N = cnt * pn;
               o_D = cnt * dk;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
                 const double rr = 1.0 / SigN;
                 const double nk = pn * rr;
                 double dk = bn * rr + (-tk * nk + dtk * (1.0 - nk));
-                if (dk < 0.0) dk = 0.0;
+                dk = __builtin_fmax(dk, 0.0);
                 o_w = cnt * (u * rr);
                 o_N = cnt * nk;
                 o_D = cnt * dk;
@@ -638,9 +638,9 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
             // sum_b c_b (exp(B_e - Z_b) - t_e num_e(b) + dt_e integ_e(b)) over the shared bins of later epochs;
             // the reference clamps every bin's term at 0 (coal_EM.cpp:277), here the (non-negative) sums are
             double integ = Cn[c] - PWn * RSn[c];  // sum_b c_b (1 - r_b PW_{e+1})
-            if (integ < 0.0) integ = 0.0;
+            integ = __builtin_fmax(integ, 0.0);
             double dsh = VW * RSn[c] + dt_e[c] * integ;
-            if (dsh < 0.0) dsh = 0.0;
+            dsh = __builtin_fmax(dsh, 0.0);
             Dpart[c] = dsh + oD[c];
           } else {
             Dpart[c] = oD[c];
@@ -674,11 +674,11 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
             }
             // later not-shared bins contribute dt_e each, earlier ones their tail mass
             double dns = dt_e[c] * Cn[c] + ((beta_e[c] - t_e[c] * p_e[c]) * T[c] + dt_e[c] * Gn * (q_e[c] * T[c]));
-            if (dns < 0.0) dns = 0.0;
+            dns = __builtin_fmax(dns, 0.0);
             Dpart[c] = dns + oD[c];
           } else {
             double dns = (beta_e[c] - t_e[c] * p_e[c]) * T[c];
-            if (dns < 0.0) dns = 0.0;
+            dns = __builtin_fmax(dns, 0.0);
             Dpart[c] = dns + oD[c];
           }
         }
