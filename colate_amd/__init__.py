@@ -16,6 +16,8 @@ from .api import (  # noqa: F401
     Rng,
     age_grid,
     bootstrap_counts,
+    bootstrap_counts_device,
+    bootstrap_weights,
     coal_EM,
     device_count,
     em_batch,

@@ -47,6 +47,10 @@ SIGNATURES = {
     "colate_rng_create": (c_void_p, [ctypes.c_uint]),
     "colate_rng_destroy": (None, [c_void_p]),
     "colate_bootstrap_counts": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_double] + [c_void_p] * 6),
+    "colate_bootstrap_weights": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "colate_bootstrap_counts_device": (c_int, [c_int, c_int, c_int, c_void_p, c_double] + [c_void_p] * 9),
+    "colate_bootstrap_em_batch": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_double] + [c_void_p] * 7
+                                  + [c_int, c_int, c_double, c_double] + [c_void_p] * 6),
     "colate_write_coal": (c_int, [c_char_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int]),
     "colate_mut_main": (c_int, [c_int, ctypes.POINTER(c_char_p)]),
 }

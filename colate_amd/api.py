@@ -78,6 +78,30 @@ def bootstrap_counts(rng, num_bootstrap, age_grid_, age, sh_block, ns_block, sh_
     return csh, cns
 
 
+def bootstrap_weights(rng, num_bootstrap, nb):
+    """coal.cpp:3350-3357: multinomial block weights [num_bootstrap][nb] from the shared mt19937."""
+    w = np.zeros((num_bootstrap, nb))
+    check(lib.colate_bootstrap_weights(rng.h, num_bootstrap, nb, _p(w)))
+    return w
+
+
+def bootstrap_counts_device(age_grid_, age, weights, sh_block, ns_block, sh_emp_block, ns_emp_block, cnt_shared,
+                            cnt_notshared, stream=None):
+    """colate_bootstrap_counts_device on torch tensors in HBM (float64, contiguous); asynchronous."""
+    B, nb = weights.shape
+    A = age_grid_.numel()
+    for t in (age_grid_, weights, sh_block, ns_block, sh_emp_block, ns_emp_block, cnt_shared, cnt_notshared):
+        assert t.is_cuda and t.is_contiguous()
+    import torch
+
+    status = torch.zeros(1, dtype=torch.int32, device=weights.device)
+    check(lib.colate_bootstrap_counts_device(B, nb, A, age_grid_.data_ptr(), float(age), weights.data_ptr(),
+                                             sh_block.data_ptr(), ns_block.data_ptr(), sh_emp_block.data_ptr(),
+                                             ns_emp_block.data_ptr(), cnt_shared.data_ptr(), cnt_notshared.data_ptr(),
+                                             status.data_ptr(), _stream_ptr(stream)))
+    return status
+
+
 def write_coal(path, epochs, rates, is_ancient=False, ep_null=0):
     e = _f64(epochs)
     r = _f64(np.atleast_2d(rates))

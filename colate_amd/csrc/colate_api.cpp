@@ -203,6 +203,90 @@ int colate_em_batch(int B, int E, int A, const double* age_grid, const double* c
   return COLATE_OK;
 }
 
+int colate_bootstrap_counts_device(int B, int nb, int A, const double* age_grid, double age,
+                                   const double* weights, const double* sh_block, const double* ns_block,
+                                   const double* sh_emp_block, const double* ns_emp_block,
+                                   double* cnt_shared, double* cnt_notshared, int* status,
+                                   void* hip_stream) {
+  if (B < 0 || nb < 1 || A < 2 || A > COLATE_EM_MAX_A) return fail(COLATE_EINVAL, "bad sizes B=%d nb=%d A=%d", B, nb, A);
+  if (!age_grid || !weights || !sh_block || !ns_block || !sh_emp_block || !ns_emp_block || !cnt_shared ||
+      !cnt_notshared)
+    return fail(COLATE_EINVAL, "NULL pointer argument");
+  if (B == 0) return COLATE_OK;
+  DevBuf scratch;
+  int* st = status;
+  if (!st) {  // the kernel always reports; give it somewhere to write
+    HIP_TRY(scratch.alloc(sizeof(int)));
+    HIP_TRY(hipMemsetAsync(scratch.p, 0, sizeof(int), static_cast<hipStream_t>(hip_stream)));
+    st = scratch.as<int>();
+  }
+  hipError_t e = colate_bootstrap_launch(B, nb, A, age_grid, age, weights, sh_block, ns_block, sh_emp_block,
+                                         ns_emp_block, cnt_shared, cnt_notshared, st,
+                                         static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "bootstrap kernel launch");
+  if (!status) HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));  // scratch dies with this call
+  return COLATE_OK;
+}
+
+int colate_bootstrap_em_batch(int B, int nb, int E, int A, const double* age_grid, double age,
+                              const double* weights, const double* sh_block, const double* ns_block,
+                              const double* sh_emp_block, const double* ns_emp_block,
+                              const double* epochs, const double* init_rates, int max_iter,
+                              int min_iter, double rel_tol, double rate_floor, double* out_rates,
+                              int* out_iters, double* out_loglik, int* out_flags,
+                              double* out_cnt_shared, double* out_cnt_notshared) {
+  if (int rc = check_sizes(B, E, A)) return rc;
+  if (nb < 1 || A < 2) return fail(COLATE_EINVAL, "bad sizes nb=%d A=%d", nb, A);
+  if (!age_grid || !weights || !sh_block || !ns_block || !sh_emp_block || !ns_emp_block || !epochs ||
+      !init_rates || !out_rates || !out_iters || !out_loglik || !out_flags)
+    return fail(COLATE_EINVAL, "NULL pointer argument");
+  if (int rc = check_grids(E, A, age_grid, epochs)) return rc;
+  if (int rc = ensure_device()) return rc;
+  if (B == 0) return COLATE_OK;
+  const size_t nT = (size_t)nb * A, nBA = (size_t)B * A, nBE = (size_t)B * E;
+  DevBuf d_grid, d_w, d_t[4], d_sh, d_ns, d_ep, d_init, d_rates, d_iters, d_ll, d_flags, d_status;
+  HIP_TRY(d_grid.alloc(A * sizeof(double)));
+  HIP_TRY(d_w.alloc((size_t)B * nb * sizeof(double)));
+  const double* tabs[4] = {sh_block, ns_block, sh_emp_block, ns_emp_block};
+  for (int k = 0; k < 4; k++) {
+    HIP_TRY(d_t[k].alloc(nT * sizeof(double)));
+    HIP_TRY(hipMemcpy(d_t[k].p, tabs[k], nT * sizeof(double), hipMemcpyHostToDevice));
+  }
+  HIP_TRY(d_sh.alloc(nBA * sizeof(double)));
+  HIP_TRY(d_ns.alloc(nBA * sizeof(double)));
+  HIP_TRY(d_ep.alloc(E * sizeof(double)));
+  HIP_TRY(d_init.alloc(E * sizeof(double)));
+  HIP_TRY(d_rates.alloc(nBE * sizeof(double)));
+  HIP_TRY(d_iters.alloc(B * sizeof(int)));
+  HIP_TRY(d_ll.alloc(B * sizeof(double)));
+  HIP_TRY(d_flags.alloc(B * sizeof(int)));
+  HIP_TRY(d_status.alloc(sizeof(int)));
+  HIP_TRY(hipMemset(d_status.p, 0, sizeof(int)));
+  HIP_TRY(hipMemcpy(d_grid.p, age_grid, A * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_w.p, weights, (size_t)B * nb * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_ep.p, epochs, E * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_init.p, init_rates, E * sizeof(double), hipMemcpyHostToDevice));
+  int rc = colate_bootstrap_counts_device(B, nb, A, d_grid.as<double>(), age, d_w.as<double>(), d_t[0].as<double>(),
+                                          d_t[1].as<double>(), d_t[2].as<double>(), d_t[3].as<double>(),
+                                          d_sh.as<double>(), d_ns.as<double>(), d_status.as<int>(), nullptr);
+  if (rc) return rc;
+  rc = colate_em_batch_device(B, E, A, d_grid.as<double>(), d_sh.as<double>(), d_ns.as<double>(), d_ep.as<double>(), 0,
+                              d_init.as<double>(), 0, max_iter, min_iter, rel_tol, rate_floor, d_rates.as<double>(),
+                              d_iters.as<int>(), d_ll.as<double>(), d_flags.as<int>(), nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  int status = 0;
+  HIP_TRY(hipMemcpy(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (status) return fail(COLATE_EINVAL, "sample age outside the age grid");
+  HIP_TRY(hipMemcpy(out_rates, d_rates.p, nBE * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_iters, d_iters.p, B * sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_loglik, d_ll.p, B * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_flags, d_flags.p, B * sizeof(int), hipMemcpyDeviceToHost));
+  if (out_cnt_shared) HIP_TRY(hipMemcpy(out_cnt_shared, d_sh.p, nBA * sizeof(double), hipMemcpyDeviceToHost));
+  if (out_cnt_notshared) HIP_TRY(hipMemcpy(out_cnt_notshared, d_ns.p, nBA * sizeof(double), hipMemcpyDeviceToHost));
+  return COLATE_OK;
+}
+
 int colate_em_batch_rows(int B, int E, int A, const double* age_grid, const double* cnt_shared,
                          const double* cnt_notshared, const double* epochs, const double* init_rates,
                          int max_iter, int min_iter, double rel_tol, double rate_floor,

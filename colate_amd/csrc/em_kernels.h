@@ -35,3 +35,9 @@ struct ColateEmArgs {
 
 size_t colate_em_lds_bytes(int E, int A);
 hipError_t colate_em_launch(const ColateEmArgs& args, hipStream_t stream);
+
+// block bootstrap on the device (bootstrap_kernel.hip)
+hipError_t colate_bootstrap_launch(int B, int nb, int A, const double* age_grid, double age,
+                                   const double* weights, const double* sh_block, const double* ns_block,
+                                   const double* sh_emp_block, const double* ns_emp_block, double* cnt_sh,
+                                   double* cnt_ns, int* status, hipStream_t stream);

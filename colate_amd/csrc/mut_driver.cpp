@@ -465,6 +465,9 @@ bool file_exists(const std::string& p) {
   return true;
 }
 
+void write_counts_file(const std::string& path, int B, int A, const std::vector<double>& grid,
+                       const double* csh, const double* cns);
+
 int run_mut(const Options& opt) {
   if (!opt.has("mut") || !opt.has("output")) {  // coal.cpp:3077-3087
     std::cout << "Not enough arguments supplied." << std::endl;
@@ -514,7 +517,9 @@ int run_mut(const Options& opt) {
   }
   const std::string out = opt.get("output");
 
-  std::vector<double> csh, cns;
+  std::vector<double> csh, cns, fsh, fns, fshe, fnse, weights;
+  int num_blocks = 0;
+  bool gpu_bootstrap = false;
   const std::string mat = out + ".colate_mat";
   if (file_exists(mat)) {  // coal.cpp:3169-3170, 3471-3499
     std::cerr << "Loading precomputed file " << mat << std::endl;
@@ -548,17 +553,28 @@ int run_mut(const Options& opt) {
       return 1;
     }
     // block bootstrap + F redistribution (coal.cpp:3326-3451) on flat [nb][A] tables
-    std::vector<double> fsh((size_t)nb * A), fns((size_t)nb * A), fshe((size_t)nb * A), fnse((size_t)nb * A);
+    fsh.resize((size_t)nb * A), fns.resize((size_t)nb * A), fshe.resize((size_t)nb * A), fnse.resize((size_t)nb * A);
     for (int j = 0; j < nb; j++) {
       std::copy(tab.sh[j].begin(), tab.sh[j].end(), fsh.begin() + (size_t)j * A);
       std::copy(tab.ns[j].begin(), tab.ns[j].end(), fns.begin() + (size_t)j * A);
       std::copy(tab.sh_emp[j].begin(), tab.sh_emp[j].end(), fshe.begin() + (size_t)j * A);
       std::copy(tab.ns_emp[j].begin(), tab.ns_emp[j].end(), fnse.begin() + (size_t)j * A);
     }
+    num_blocks = nb;
     csh.assign((size_t)B * A, 0.0);
     cns.assign((size_t)B * A, 0.0);
-    if (int rc = colate_bootstrap_counts(&rng, B, nb, A, age_grid.data(), age, fsh.data(), fns.data(),
-                                         fshe.data(), fnse.data(), csh.data(), cns.data())) {
+    // the weights come from the run's mt19937 either way (coal.cpp:3350-3357); the weighted sums and
+    // the F redistribution run on the GPU together with the EM unless only the counts are wanted
+    // (--counts_only, no device needed) or the replicates are sharded over several GPUs
+    gpu_bootstrap = !opt.has("counts_only") && !opt.has("devices");
+    if (gpu_bootstrap) {
+      weights.resize((size_t)B * nb);
+      if (int rc = colate_bootstrap_weights(&rng, B, nb, weights.data())) {
+        std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
+        return 1;
+      }
+    } else if (int rc = colate_bootstrap_counts(&rng, B, nb, A, age_grid.data(), age, fsh.data(), fns.data(),
+                                                fshe.data(), fnse.data(), csh.data(), cns.data())) {
       std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
       return 1;
     }
@@ -569,21 +585,11 @@ int run_mut(const Options& opt) {
     return 1;
   }
 
-  if (opt.has("counts_out")) {  // same layout as the reference's .colate_mat (coal.cpp:3336-3343, 3453-3469)
-    FILE* f = std::fopen(opt.get("counts_out").c_str(), "w");
-    if (!f) {
-      std::cerr << "Error: cannot write " << opt.get("counts_out") << std::endl;
-      return 1;
-    }
-    for (int b = 0; b < A; b++) std::fprintf(f, "%.17g ", age_grid[b]);
-    std::fprintf(f, "\n");
-    for (int i = 0; i < B; i++) {
-      for (int b = 0; b < A; b++) std::fprintf(f, "%.17g ", csh[(size_t)i * A + b]);
-      std::fprintf(f, "\n");
-      for (int b = 0; b < A; b++) std::fprintf(f, "%.17g ", cns[(size_t)i * A + b]);
-      std::fprintf(f, "\n");
-    }
-    std::fclose(f);
+  auto write_counts = [&]() {  // same layout as the reference's .colate_mat (coal.cpp:3336-3343, 3453-3469)
+    write_counts_file(opt.get("counts_out"), B, A, age_grid, csh.data(), cns.data());
+  };
+  if (opt.has("counts_out") && !gpu_bootstrap) {
+    write_counts();
     if (opt.has("counts_only")) return 0;
   }
 
@@ -631,6 +637,12 @@ int run_mut(const Options& opt) {
                                  epochs.data(), init_rates.data(), COLATE_DEFAULT_MAX_ITER,
                                  COLATE_DEFAULT_MIN_ITER, COLATE_DEFAULT_REL_TOL, COLATE_DEFAULT_RATE_FLOOR,
                                  rates.data(), iters.data(), ll.data(), flags.data());
+  } else if (gpu_bootstrap) {
+    rc = colate_bootstrap_em_batch(B, num_blocks, E, A, age_grid.data(), age, weights.data(), fsh.data(), fns.data(),
+                                   fshe.data(), fnse.data(), epochs.data(), init_rates.data(), COLATE_DEFAULT_MAX_ITER,
+                                   COLATE_DEFAULT_MIN_ITER, COLATE_DEFAULT_REL_TOL, COLATE_DEFAULT_RATE_FLOOR,
+                                   rates.data(), iters.data(), ll.data(), flags.data(), csh.data(), cns.data());
+    if (rc == 0 && opt.has("counts_out")) write_counts();
   } else {
     rc = colate_em_batch(B, E, A, age_grid.data(), csh.data(), cns.data(), epochs.data(),
                          init_rates.data(), COLATE_DEFAULT_MAX_ITER, COLATE_DEFAULT_MIN_ITER,

@@ -147,6 +147,23 @@ void* colate_rng_create(unsigned int seed) {
 
 void colate_rng_destroy(void* rng_state) { delete static_cast<std::mt19937*>(rng_state); }
 
+// coal.cpp:3350-3357
+int colate_bootstrap_weights(void* rng_state, int num_bootstrap, int nb, double* weights) {
+  if (!rng_state || !weights || num_bootstrap < 1 || nb < 1) return fail(COLATE_EINVAL, "bad argument");
+  std::mt19937& rng = *static_cast<std::mt19937*>(rng_state);
+  std::uniform_int_distribution<int> dist_blocks(0, nb - 1);
+  for (int i = 0; i < num_bootstrap; i++) {
+    double* w = weights + (size_t)i * nb;
+    if (num_bootstrap == 1) {
+      std::fill(w, w + nb, 1.0);
+    } else {
+      std::fill(w, w + nb, 0.0);
+      for (int j = 0; j < nb; j++) w[dist_blocks(rng)] += 1.0;
+    }
+  }
+  return COLATE_OK;
+}
+
 // coal.cpp:3344-3451 for all replicates (the emp tables are reduced to the row the
 // reference reads: bin1 == 0, coal.cpp:3397)
 int colate_bootstrap_counts(void* rng_state, int num_bootstrap, int nb, int A,

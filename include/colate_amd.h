@@ -146,6 +146,33 @@ int colate_bootstrap_counts(void* rng_state, int num_bootstrap, int nb, int A,
                             const double* ns_emp_block, double* cnt_shared,
                             double* cnt_notshared);
 
+/* coal.cpp:3350-3357 alone: the multinomial block weights w[num_bootstrap][nb] (all ones when
+ * num_bootstrap == 1), drawn from the same std::mt19937 -- the host half of the GPU bootstrap below. */
+int colate_bootstrap_weights(void* rng_state, int num_bootstrap, int nb, double* weights);
+
+/* coal.cpp:3358-3441 on the GPU: weighted block sums + F redistribution for B replicates, all
+ * pointers in device memory (tables [nb][A], weights [B][nb], cnt_* [B][A]), asynchronous on
+ * hip_stream; results are bit-identical to colate_bootstrap_counts.  `status` (device int, may be
+ * NULL) receives 1 if the sample age lies outside the age grid. */
+int colate_bootstrap_counts_device(int B, int nb, int A, const double* age_grid, double age,
+                                   const double* weights, const double* sh_block, const double* ns_block,
+                                   const double* sh_emp_block, const double* ns_emp_block,
+                                   double* cnt_shared, double* cnt_notshared, int* status,
+                                   void* hip_stream);
+
+/* Block tables -> rates in one call, host pointers: uploads the [nb][A] tables and the weights
+ * w[B][nb], runs the bootstrap kernel and the EM kernel back to back on the device (the count
+ * tables never visit the host) and returns the EM outputs; out_cnt_shared / out_cnt_notshared
+ * (each [B][A], may be NULL) additionally receive the count tables.  This is what `Colate --mode
+ * mut` of colate_amd runs after reading the inputs (coal.cpp:3344-3451 + 3675-3827). */
+int colate_bootstrap_em_batch(int B, int nb, int E, int A, const double* age_grid, double age,
+                              const double* weights, const double* sh_block, const double* ns_block,
+                              const double* sh_emp_block, const double* ns_emp_block,
+                              const double* epochs, const double* init_rates, int max_iter,
+                              int min_iter, double rel_tol, double rate_floor, double* out_rates,
+                              int* out_iters, double* out_loglik, int* out_flags,
+                              double* out_cnt_shared, double* out_cnt_notshared);
+
 /* coal.cpp:3660-3672, 3830-3847: the .coal text (6 significant digits, trailing blank). */
 int colate_write_coal(const char* path, int B, int E, const double* epochs, const double* rates,
                       int is_ancient, int ep_null);

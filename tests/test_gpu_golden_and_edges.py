@@ -282,3 +282,43 @@ def test_flags(ca):
     init[-1] = 0.0
     num, den, ll, fl = ca.em_estep(grid, csh, cns2, ep, np.tile(init, (2, 1)))
     assert (fl & ca.FLAG_NAN).all()
+
+
+def test_device_bootstrap_bit_identical_to_host(ca):
+    """Block bootstrap on the GPU (weighted block sums + F redistribution, coal.cpp:3358-3441) against
+    the host path, same std::mt19937 weights: bit-identical tables, then EM straight from HBM."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    grid = ol.age_grid()
+    A, nb, B = grid.size, 115, 64
+    sh = rng.uniform(0, 3, (nb, A)) * (rng.uniform(size=(nb, A)) < 0.6)
+    ns = rng.uniform(0, 9, (nb, A)) * (rng.uniform(size=(nb, A)) < 0.6)
+    she = rng.uniform(0, 1, (nb, A)) * (rng.uniform(size=(nb, A)) < 0.2)
+    nse = rng.uniform(0, 1, (nb, A)) * (rng.uniform(size=(nb, A)) < 0.2)
+    sh[:, :30] = ns[:, :30] = she[:, :30] = nse[:, :30] = 0
+    dev = torch.device("cuda")
+    f64 = dict(dtype=torch.float64, device=dev)
+    for age in (0.0, 250.0):
+        for nboot in (1, B):
+            h_sh, h_ns = ca.bootstrap_counts(ca.Rng(777), nboot, grid, age, sh, ns, she, nse)
+            w = ca.bootstrap_weights(ca.Rng(777), nboot, nb)
+            d_sh = torch.empty((nboot, A), **f64)
+            d_ns = torch.empty((nboot, A), **f64)
+            status = ca.bootstrap_counts_device(torch.tensor(grid, **f64), age, torch.tensor(w, **f64), torch.tensor(sh, **f64),
+                                                torch.tensor(ns, **f64), torch.tensor(she, **f64), torch.tensor(nse, **f64),
+                                                d_sh, d_ns)
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0
+            assert np.array_equal(d_sh.cpu().numpy(), h_sh) and np.array_equal(d_ns.cpu().numpy(), h_ns)
+    # and on into the EM without leaving HBM
+    ep, _ = ol.epochs_from_bins("3,7,0.2")
+    E = ep.size
+    out = torch.empty((B, E), **f64)
+    it = torch.empty(B, dtype=torch.int32, device=dev)
+    ll = torch.empty(B, **f64)
+    fl = torch.empty(B, dtype=torch.int32, device=dev)
+    ca.em_batch_device(torch.tensor(grid, **f64), d_sh, d_ns, torch.tensor(ep, **f64),
+                       torch.full((E,), ca.DEFAULT_INIT_RATE, **f64), out, it, ll, fl, max_iter=60)
+    r0, it0, _, _ = ca.em_batch(grid, h_sh, h_ns, ep, max_iter=60)
+    assert np.array_equal(out.cpu().numpy(), r0)
