@@ -23,6 +23,7 @@ from .api import (  # noqa: F401
     em_batch,
     em_batch_device,
     em_batch_rows,
+    em_batch_rows_sharded,
     em_batch_sharded,
     em_estep,
     em_estep_device,

@@ -39,6 +39,9 @@ SIGNATURES = {
                                      c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "colate_em_batch_sharded": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "colate_em_batch_rows_sharded": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p,
+                                             c_void_p]),
     "colate_em_estep": (c_int, [c_int, c_int, c_int] + [c_void_p] * 9),
     "colate_em_estep_device": (c_int, [c_int, c_int, c_int] + [c_void_p] * 10),
     "colate_age_grid": (c_int, [c_void_p, c_int]),

@@ -165,6 +165,27 @@ def em_batch_sharded(devices, age_grid_, cnt_shared, cnt_notshared, epochs, init
     return rates, iters, ll, flags
 
 
+def em_batch_rows_sharded(devices, age_grid_, cnt_shared, cnt_notshared, epochs, init_rates=None,
+                          max_iter=DEFAULT_MAX_ITER, min_iter=DEFAULT_MIN_ITER, rel_tol=DEFAULT_REL_TOL,
+                          rate_floor=DEFAULT_RATE_FLOOR):
+    """colate_em_batch_rows_sharded: per-row epochs[B][E] (batched pairs), rows sharded over `devices`."""
+    g, sh, ns = _f64(age_grid_), _f64(np.atleast_2d(cnt_shared)), _f64(np.atleast_2d(cnt_notshared))
+    ep = _f64(np.atleast_2d(epochs))
+    B, A = sh.shape
+    E = ep.shape[1]
+    assert ep.shape == (B, E)
+    init = _f64(np.full((B, E), DEFAULT_INIT_RATE) if init_rates is None else np.atleast_2d(init_rates))
+    assert init.shape == (B, E)
+    dev = np.ascontiguousarray(devices, dtype=np.int32)
+    rates = np.zeros((B, E))
+    iters = np.zeros(B, dtype=np.int32)
+    ll = np.zeros(B)
+    flags = np.zeros(B, dtype=np.int32)
+    check(lib.colate_em_batch_rows_sharded(dev.size, _p(dev), B, E, A, _p(g), _p(sh), _p(ns), _p(ep), _p(init), max_iter,
+                                           min_iter, rel_tol, rate_floor, _p(rates), _p(iters), _p(ll), _p(flags)))
+    return rates, iters, ll, flags
+
+
 def em_estep(age_grid_, cnt_shared, cnt_notshared, epochs, rates):
     """colate_em_estep on host arrays: rates[B][E] -> (num[B][E], den[B][E], loglik[B], flags[B])."""
     g, sh, ns, ep = _f64(age_grid_), _f64(np.atleast_2d(cnt_shared)), _f64(np.atleast_2d(cnt_notshared)), _f64(epochs)

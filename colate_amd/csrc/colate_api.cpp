@@ -328,18 +328,20 @@ int colate_em_batch_rows(int B, int E, int A, const double* age_grid, const doub
   return COLATE_OK;
 }
 
-int colate_em_batch_sharded(int num_devices, const int* devices, int B, int E, int A,
-                            const double* age_grid, const double* cnt_shared,
-                            const double* cnt_notshared, const double* epochs,
-                            const double* init_rates, int max_iter, int min_iter, double rel_tol,
-                            double rate_floor, double* out_rates, int* out_iters, double* out_loglik,
-                            int* out_flags) {
+// per_row: epochs and init_rates are [B][E] (one grid per replicate row) instead of [E]
+static int em_batch_sharded_impl(bool per_row, int num_devices, const int* devices, int B, int E, int A,
+                                 const double* age_grid, const double* cnt_shared,
+                                 const double* cnt_notshared, const double* epochs,
+                                 const double* init_rates, int max_iter, int min_iter, double rel_tol,
+                                 double rate_floor, double* out_rates, int* out_iters, double* out_loglik,
+                                 int* out_flags) {
   if (num_devices < 1 || !devices) return fail(COLATE_EINVAL, "need at least one device");
   if (int rc = check_sizes(B, E, A)) return rc;
   if (!age_grid || !cnt_shared || !cnt_notshared || !epochs || !init_rates || !out_rates ||
       !out_iters || !out_loglik || !out_flags)
     return fail(COLATE_EINVAL, "NULL pointer argument");
-  if (int rc = check_grids(E, A, age_grid, epochs)) return rc;
+  for (int b = 0; b < (per_row ? B : 1); b++)
+    if (int rc = check_grids(E, A, age_grid, epochs + (size_t)b * E)) return rc;
   if (int rc = ensure_device()) return rc;
   int ndev_avail = 0;
   HIP_TRY(hipGetDeviceCount(&ndev_avail));
@@ -363,6 +365,7 @@ int colate_em_batch_sharded(int num_devices, const int* devices, int B, int E, i
     s.n = base + (d < rem ? 1 : 0);
     if (s.n == 0) continue;
     const size_t nA = (size_t)s.n * A, nE = (size_t)s.n * E;
+    const size_t nEp = per_row ? nE : (size_t)E, ep_off = per_row ? (size_t)s.lo * E : 0;  // this shard's epoch rows
     auto step = [&](hipError_t e, const char* what) {
       if (e != hipSuccess && rc == COLATE_OK) rc = hip_fail(e, what);
       return e == hipSuccess;
@@ -370,21 +373,21 @@ int colate_em_batch_sharded(int num_devices, const int* devices, int B, int E, i
     if (!step(hipSetDevice(devices[d]), "hipSetDevice")) break;
     if (!step(hipStreamCreate(&s.stream), "hipStreamCreate")) break;
     bool ok = step(s.grid.alloc(A * sizeof(double)), "hipMalloc") && step(s.sh.alloc(nA * sizeof(double)), "hipMalloc") &&
-              step(s.ns.alloc(nA * sizeof(double)), "hipMalloc") && step(s.ep.alloc(E * sizeof(double)), "hipMalloc") &&
-              step(s.init.alloc(E * sizeof(double)), "hipMalloc") && step(s.rates.alloc(nE * sizeof(double)), "hipMalloc") &&
+              step(s.ns.alloc(nA * sizeof(double)), "hipMalloc") && step(s.ep.alloc(nEp * sizeof(double)), "hipMalloc") &&
+              step(s.init.alloc(nEp * sizeof(double)), "hipMalloc") && step(s.rates.alloc(nE * sizeof(double)), "hipMalloc") &&
               step(s.iters.alloc(s.n * sizeof(int)), "hipMalloc") && step(s.ll.alloc(s.n * sizeof(double)), "hipMalloc") &&
               step(s.flags.alloc(s.n * sizeof(int)), "hipMalloc");
     if (!ok) break;
     ok = step(hipMemcpyAsync(s.grid.p, age_grid, A * sizeof(double), hipMemcpyHostToDevice, s.stream), "copy") &&
          step(hipMemcpyAsync(s.sh.p, cnt_shared + (size_t)s.lo * A, nA * sizeof(double), hipMemcpyHostToDevice, s.stream), "copy") &&
          step(hipMemcpyAsync(s.ns.p, cnt_notshared + (size_t)s.lo * A, nA * sizeof(double), hipMemcpyHostToDevice, s.stream), "copy") &&
-         step(hipMemcpyAsync(s.ep.p, epochs, E * sizeof(double), hipMemcpyHostToDevice, s.stream), "copy") &&
-         step(hipMemcpyAsync(s.init.p, init_rates, E * sizeof(double), hipMemcpyHostToDevice, s.stream), "copy");
+         step(hipMemcpyAsync(s.ep.p, epochs + ep_off, nEp * sizeof(double), hipMemcpyHostToDevice, s.stream), "copy") &&
+         step(hipMemcpyAsync(s.init.p, init_rates + ep_off, nEp * sizeof(double), hipMemcpyHostToDevice, s.stream), "copy");
     if (!ok) break;
     int r2 = colate_em_batch_device(s.n, E, A, s.grid.as<double>(), s.sh.as<double>(), s.ns.as<double>(),
-                                    s.ep.as<double>(), 0, s.init.as<double>(), 0, max_iter, min_iter, rel_tol,
-                                    rate_floor, s.rates.as<double>(), s.iters.as<int>(), s.ll.as<double>(),
-                                    s.flags.as<int>(), s.stream);
+                                    s.ep.as<double>(), per_row ? 1 : 0, s.init.as<double>(), per_row ? 1 : 0, max_iter,
+                                    min_iter, rel_tol, rate_floor, s.rates.as<double>(), s.iters.as<int>(),
+                                    s.ll.as<double>(), s.flags.as<int>(), s.stream);
     if (r2) {
       rc = r2;
       break;
@@ -410,6 +413,28 @@ int colate_em_batch_sharded(int num_devices, const int* devices, int B, int E, i
   }
   (void)hipSetDevice(prev_dev);
   return rc;
+}
+
+int colate_em_batch_sharded(int num_devices, const int* devices, int B, int E, int A,
+                            const double* age_grid, const double* cnt_shared,
+                            const double* cnt_notshared, const double* epochs,
+                            const double* init_rates, int max_iter, int min_iter, double rel_tol,
+                            double rate_floor, double* out_rates, int* out_iters, double* out_loglik,
+                            int* out_flags) {
+  return em_batch_sharded_impl(false, num_devices, devices, B, E, A, age_grid, cnt_shared, cnt_notshared, epochs,
+                               init_rates, max_iter, min_iter, rel_tol, rate_floor, out_rates, out_iters, out_loglik,
+                               out_flags);
+}
+
+int colate_em_batch_rows_sharded(int num_devices, const int* devices, int B, int E, int A,
+                                 const double* age_grid, const double* cnt_shared,
+                                 const double* cnt_notshared, const double* epochs,
+                                 const double* init_rates, int max_iter, int min_iter, double rel_tol,
+                                 double rate_floor, double* out_rates, int* out_iters, double* out_loglik,
+                                 int* out_flags) {
+  return em_batch_sharded_impl(true, num_devices, devices, B, E, A, age_grid, cnt_shared, cnt_notshared, epochs,
+                               init_rates, max_iter, min_iter, rel_tol, rate_floor, out_rates, out_iters, out_loglik,
+                               out_flags);
 }
 
 int colate_em_estep(int B, int E, int A, const double* age_grid, const double* cnt_shared,

@@ -812,6 +812,15 @@ int run_mut_pairs(const Options& opt) {
       return 1;
     }
   }
+  std::vector<int> dev_list;
+  if (opt.has("devices")) {
+    const int nd = std::stoi(opt.get("devices"));
+    if (nd < 1) {
+      std::cerr << "Error: --devices must be at least 1." << std::endl;
+      return 1;
+    }
+    for (int d = 0; d < nd; d++) dev_list.push_back(d);
+  }
   std::vector<bool> done(P, false);
   for (size_t p0 = 0; p0 < P; p0++) {  // one launch per distinct number of epochs
     if (done[p0]) continue;
@@ -828,9 +837,17 @@ int run_mut_pairs(const Options& opt) {
       std::copy(cns[p].begin(), cns[p].end(), g_ns.begin() + k * B * A);
       for (int i = 0; i < B; i++) std::copy(epochs[p].begin(), epochs[p].end(), g_ep.begin() + (k * B + i) * E);
     }
-    if (int rc = colate_em_batch_rows((int)R, E, A, age_grid.data(), g_sh.data(), g_ns.data(), g_ep.data(), g_init.data(),
-                                      COLATE_DEFAULT_MAX_ITER, COLATE_DEFAULT_MIN_ITER, COLATE_DEFAULT_REL_TOL,
-                                      COLATE_DEFAULT_RATE_FLOOR, g_rates.data(), g_it.data(), g_ll.data(), g_fl.data())) {
+    int rc;
+    if (!dev_list.empty())  // --devices N: the rows (pairs x replicates) shard over GPUs 0..N-1
+      rc = colate_em_batch_rows_sharded((int)dev_list.size(), dev_list.data(), (int)R, E, A, age_grid.data(), g_sh.data(),
+                                        g_ns.data(), g_ep.data(), g_init.data(), COLATE_DEFAULT_MAX_ITER,
+                                        COLATE_DEFAULT_MIN_ITER, COLATE_DEFAULT_REL_TOL, COLATE_DEFAULT_RATE_FLOOR,
+                                        g_rates.data(), g_it.data(), g_ll.data(), g_fl.data());
+    else
+      rc = colate_em_batch_rows((int)R, E, A, age_grid.data(), g_sh.data(), g_ns.data(), g_ep.data(), g_init.data(),
+                                COLATE_DEFAULT_MAX_ITER, COLATE_DEFAULT_MIN_ITER, COLATE_DEFAULT_REL_TOL,
+                                COLATE_DEFAULT_RATE_FLOOR, g_rates.data(), g_it.data(), g_ll.data(), g_fl.data());
+    if (rc) {
       std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
       return 1;
     }

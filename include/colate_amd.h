@@ -107,6 +107,15 @@ int colate_em_batch_sharded(int num_devices, const int* devices, int B, int E, i
                             double rate_floor, double* out_rates, int* out_iters, double* out_loglik,
                             int* out_flags);
 
+/* The same sharding for the per-row form (epochs[B][E], init_rates[B][E], as colate_em_batch_rows):
+ * the batched all-pairs run over several GPUs. */
+int colate_em_batch_rows_sharded(int num_devices, const int* devices, int B, int E, int A,
+                                 const double* age_grid, const double* cnt_shared,
+                                 const double* cnt_notshared, const double* epochs,
+                                 const double* init_rates, int max_iter, int min_iter, double rel_tol,
+                                 double rate_floor, double* out_rates, int* out_iters,
+                                 double* out_loglik, int* out_flags);
+
 /* One E-step = one pass of coal.cpp:3698-3733 for each of B replicates with the
  * rates given per replicate: rates[B][E] -> num_acc[B][E], den_acc[B][E]
  * (coal_rates_num / coal_rates_denom), loglik[B], flags[B]. */

@@ -225,6 +225,29 @@ def test_sharded_entry_point_matches_single_launch(ca):
         ca.em_batch_sharded([99], grid, csh, cns, ep)
 
 
+def test_rows_sharded_entry_point_matches_rows_launch(ca):
+    """colate_em_batch_rows_sharded: per-row epochs (batched pairs) sharded over devices/streams; rows come
+    back in order, bit-identical to colate_em_batch_rows."""
+    from colate_amd import workloads
+
+    grid = ol.age_grid()
+    ep_a, _ = ol.epochs_from_bins("3,7,0.2")
+    ep_b = ep_a.copy()
+    ep_b[2:-1] *= 1.07
+    csh, cns = workloads.bootstrap_tables(grid, 7, nb=9, scale=1.0)
+    eps = np.stack([ep_a, ep_b, ep_b, ep_a, ep_a, ep_b, ep_a])
+    init = np.full(eps.shape, 1.0 / 20000.0)
+    init[3] *= 2.0
+    r1, it1, ll1, fl1 = ca.em_batch_rows(grid, csh, cns, eps, init)
+    for devs in ([0], [0, 0], [0] * 9):
+        r, it, ll, fl = ca.em_batch_rows_sharded(devs, grid, csh, cns, eps, init)
+        assert np.array_equal(r, r1) and np.array_equal(ll, ll1) and (it == it1).all() and (fl == fl1).all()
+    bad = eps.copy()
+    bad[5, 4] = bad[5, 3] - 1.0  # a decreasing epoch grid in one row is rejected for the whole call
+    with pytest.raises(ca.ColateError):
+        ca.em_batch_rows_sharded([0, 0], grid, csh, cns, bad, init)
+
+
 def test_pairs_mode_one_launch_equals_separate_runs(ca, tmp_path):
     """Batched all-pairs front end: one process, one launch per distinct epoch count; every pair's
     .coal is byte-identical to the .coal of that pair run on its own."""
@@ -240,6 +263,13 @@ def test_pairs_mode_one_launch_equals_separate_runs(ca, tmp_path):
                                              "--reference_age", ra, "-o", out + "_single"], cwd=str(tmp_path), capture_output=True)
         assert r.returncode == 0, r.stderr.decode()[-800:]
         assert (tmp_path / (out + ".coal")).read_text() == (tmp_path / (out + "_single.coal")).read_text()
+    # --devices N shards the (pair, replicate) rows over GPUs 0..N-1: same files
+    for out in ("ab", "ba", "aa"):
+        (tmp_path / (out + ".coal")).rename(tmp_path / (out + "_one.coal"))
+    r = subprocess.run([CLI] + common + ["--pairs", "pairs.txt", "--devices", "1"], cwd=str(tmp_path), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    for out in ("ab", "ba", "aa"):
+        assert (tmp_path / (out + ".coal")).read_text() == (tmp_path / (out + "_one.coal")).read_text()
 
 
 @pytest.mark.parametrize("A", [1, 2, 64, 65, 130, 256])
