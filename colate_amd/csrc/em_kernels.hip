@@ -165,8 +165,9 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// MODE 0: EM to convergence, 1: one E-step (num/den/ll out).  NCH = epoch chunks of 64 per lane.
-template <int MODE, int NCH>
+// MODE 0: EM to convergence, 1: one E-step (num/den/ll out).  NCH = epoch chunks of 64 per lane;
+// EROWS = 16-lane rows of a chunk that hold epochs (1, 2 or 4; 4 whenever NCH > 1).
+template <int MODE, int NCH, int EROWS>
 __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
   extern __shared__ double lds[];
   const int E = p.E, A = p.A;
@@ -331,7 +332,8 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
   __syncthreads();
   if (grp >= NB) return;  // waves without bins retire; later barriers count the remaining waves only
   const bool leader = (grp == 0);
-  constexpr int erows = 4;  // (skipping cross-row scan steps for E <= 32 behind uniform branches measured slower)
+  constexpr int erows = EROWS;  // 16-lane rows that hold epochs: a compile-time constant (skipping the cross-row
+                                // scan steps behind run-time uniform branches measured slower)
   const int nwave_live = 2 * NB;
   (void)nwave_live;
 
@@ -442,15 +444,20 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
       double o_w = 0, o_N = 0, o_D = 0, llp = 0.0;
       bool fail = false;
       if (live && !COLATE_ABL_HAS(12)) {
-        const double lk = s_ep[G_LAM * EPAD + kb], ik = s_ep[G_INV * EPAD + kb], ck = s_ep[G_CS * EPAD + kb];
+        const double lk = s_ep[G_LAM * EPAD + kb], ik = s_ep[G_INV * EPAD + kb];
         const bool lpos = lk > 0;
-        const double ck1 = ck + lk * da;            // coal_EM.cpp:178-181 at the merged grid
+        // -cumsum(age) at the merged grid (coal_EM.cpp:178-181): only the log-likelihood needs it
+        auto neg_cs_age = [&]() {
+          const double ck = s_ep[G_CS * EPAD + kb];
+          const double ck1 = ck + lk * da;
+          return -(ck1 + lk * (a_b - a_b));  // (second copy of `age` in the merged grid)
+        };
         if (role == 0) {  // ---- EM_shared, coal_EM.cpp:198-210, 263-287
           const double Sk = s_ep[G_S * EPAD + kb], Xak = s_ep[G_XA * EPAD + kb], PWk = s_ep[G_PW * EPAD + kb];
 #if COLATE_ABL_HAS(5)
-          const double qd = 1.0 + (-ck1 + ck);
+          const double qd = 1.0 - lk * da;
 #else
-          const double qd = em::em_exp(-ck1 + ck);
+          const double qd = em::em_exp(-(lk * da));  // exp(-cumsum(age) + cumsum(t_k)): same up to the rounding of cumsum
 #endif
 #if COLATE_ABL_HAS(8)
           const double Y = (a_b + ik) * lk;
@@ -477,20 +484,21 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
             fail = true;
           }
         } else {  // ---- EM_notshared, coal_EM.cpp:330-357, 435-460
-          const double ck2 = ck1 + lk * (a_b - a_b);  // second copy of `age` in the merged grid
           if (last_bin) {  // bin beyond the start of the last epoch, coal_EM.cpp:350-357
             if (!lpos) my_flags |= COLATE_FLAG_NAN;  // reference: assert(coal_rate_e > 0)
             double dk = (a_b + ik) - tk;
             dk = __builtin_fmax(dk, 0.0);
             o_N = cnt;
             o_D = cnt * dk;
-            llp = cnt * (-ck2);
+            if (need_ll) {
+              COLATE_COLD();
+              llp = cnt * neg_cs_age();
+            }
           } else {
-            const double ck3 = ck2 + lk * db;
 #if COLATE_ABL_HAS(6)
-            const double u = 1.0 + (-ck3 + ck2);
+            const double u = 1.0 - lk * db;
 #else
-            const double u = em::em_exp(-ck3 + ck2);
+            const double u = em::em_exp(-(lk * db));  // exp(-cumsum(t_{k+1}) + cumsum(age)), likewise
 #endif
             const double pn = lpos ? 1.0 - u : 0.0;
             const double bn = lpos ? (a_b + ik) - (tkn + ik) * u : 0.0;
@@ -500,7 +508,10 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
               o_w = cnt * u;
               o_N = cnt * pn;
               o_D = cnt * dk;
-              llp = cnt * (-ck2);
+              if (need_ll) {
+                COLATE_COLD();
+                llp = cnt * neg_cs_age();
+              }
             } else {  // last rate is 0: the mass beyond t_{k+1} is 1 - S_{E-1}/S_{k+1}
               COLATE_COLD();
               const double Gk1 = 1.0 - em::em_exp(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + kb + 1]);
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
                 o_w = cnt * (u * rr);
                 o_N = cnt * nk;
                 o_D = cnt * dk;
-                llp = cnt * (-ck2 + em::em_log(SigN));
+                llp = cnt * (neg_cs_age() + em::em_log(SigN));
               } else {
                 fail = true;
               }
@@ -809,9 +820,9 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
   }
 }
 
-template <int MODE, int NCH>
+template <int MODE, int NCH, int EROWS>
 hipError_t launch_one(const ColateEmArgs& args, hipStream_t stream, size_t lds, int threads) {
-  auto kern = em_kernel<MODE, NCH>;
+  auto kern = em_kernel<MODE, NCH, EROWS>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -840,12 +851,17 @@ hipError_t colate_em_launch(const ColateEmArgs& args, hipStream_t stream) {
   const size_t lds = colate_em_lds_bytes(args.E, args.A);
   const int threads = em_threads(args.A);
   const int nch = em_chunks(args.E);
+  const int rows = args.E <= 16 ? 1 : (args.E <= 32 ? 2 : 4);  // BASELINE's `--bins 3,7,0.2` gives E = 23
   if (args.mode == 1) {
-    if (nch == 1) return launch_one<1, 1>(args, stream, lds, threads);
-    if (nch == 2) return launch_one<1, 2>(args, stream, lds, threads);
-    return launch_one<1, 4>(args, stream, lds, threads);
+    if (nch == 1) return launch_one<1, 1, 4>(args, stream, lds, threads);
+    if (nch == 2) return launch_one<1, 2, 4>(args, stream, lds, threads);
+    return launch_one<1, 4, 4>(args, stream, lds, threads);
   }
-  if (nch == 1) return launch_one<0, 1>(args, stream, lds, threads);
-  if (nch == 2) return launch_one<0, 2>(args, stream, lds, threads);
-  return launch_one<0, 4>(args, stream, lds, threads);
+  if (nch == 1) {
+    if (rows == 1) return launch_one<0, 1, 1>(args, stream, lds, threads);
+    if (rows == 2) return launch_one<0, 1, 2>(args, stream, lds, threads);
+    return launch_one<0, 1, 4>(args, stream, lds, threads);
+  }
+  if (nch == 2) return launch_one<0, 2, 4>(args, stream, lds, threads);
+  return launch_one<0, 4, 4>(args, stream, lds, threads);
 }
