@@ -13,12 +13,12 @@ import sys
 
 def main(src, dst):
     out = []
-    for f in sorted(glob.glob(os.path.join(src, "*", "*", "*_kernel_stats.csv"))):
+    for f in sorted(glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True)):
         out.append(f"## kernel stats ({os.path.relpath(f, src)})")
         for r in csv.DictReader(open(f)):
             out.append(f"{r['Name'][:80]:80s} calls={r['Calls']:>4s} avg_ns={float(r['AverageNs']):.0f} "
                        f"min_ns={r['MinNs']} max_ns={r['MaxNs']} pct={r['Percentage']}")
-    for f in sorted(glob.glob(os.path.join(src, "*", "*", "*_counter_collection.csv"))):
+    for f in sorted(glob.glob(os.path.join(src, "**", "*_counter_collection.csv"), recursive=True)):
         rows = list(csv.DictReader(open(f)))
         agg = collections.defaultdict(list)
         meta = {}
