@@ -4,6 +4,8 @@ set -euo pipefail
 cd "$(dirname "$0")"
 make -C colate_amd/csrc
 ( cd colate_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 \
-    -I../../include -I. -Wno-unused-value tools/em_phase_probe.hip -o ../bin/em_phase_probe )
+    -I../../include -I. -Wno-unused-value tools/em_phase_probe.hip -o ../bin/em_phase_probe
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 \
+    -I../../include -I. -Wno-unused-value tools/residency_probe.hip -o ../bin/residency_probe )
 make -C oracle oracle
 echo BUILD OK

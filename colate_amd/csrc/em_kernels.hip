@@ -192,6 +192,10 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
   int* s_fail = s_kb + AP + 1;                       // [8] per-wave "a bin failed" flags
   int* s_misc = s_fail + 8;                          // [4] nzlo, nzhi, flags
 
+#ifdef COLATE_EM_TRACE  // diagnostic build (tools/residency_probe.hip): where and when this workgroup ran
+  unsigned long long trace_t0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trace_t0)::"memory");
+#endif
   // ------------------------------------------------------------------ prologue
   const double* epochs = p.epochs + (size_t)rep * p.epochs_stride;
   for (int i = tid; i < EPAD + 1; i += blockDim.x) s_t[i] = (i < E) ? epochs[i] : 0.0;
@@ -795,6 +799,17 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
   if (p.out_num && lane == 0 && MODE == 0 && leader) {  // diagnostic build: per-role phase cycles in place of out_num
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out_num) + ((size_t)rep * 4 + role) * 16;
     for (int i = 0; i < 16; i++) dbg[i] = st_acc[i];
+  }
+#endif
+#ifdef COLATE_EM_TRACE
+  if (p.out_num && tid == 0 && MODE == 0) {
+    unsigned long long trace_t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trace_t1)::"memory");
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out_num) + (size_t)rep * 4;
+    dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+    dbg[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+    dbg[2] = trace_t0;
+    dbg[3] = trace_t1;
   }
 #endif
   // ------------------------------------------------------------------ epilogue
