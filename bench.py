@@ -112,8 +112,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # COLATE_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs than
+        # ranks (ranks share devices, the gather is staged through host memory); never the measured setup
+        backend = os.environ.get("COLATE_BENCH_BACKEND", "nccl")
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -138,10 +144,19 @@ def main():
     d_flags = torch.empty((B,), dtype=torch.int32, device=dev)
     d_all = torch.empty((world * B, E), **f64) if world > 1 else None
 
+    def gather():  # the one collective: B*E doubles per rank
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(d_all, d_rates)
+        else:
+            h = d_rates.cpu()
+            h_all = torch.empty((world * B, E), dtype=torch.float64)
+            dist.all_gather_into_tensor(h_all, h)
+            d_all.copy_(h_all)
+
     def step():
         colate_amd.em_batch_device(d_grid, d_sh, d_ns, d_ep, d_init, d_rates, d_iters, d_ll, d_flags)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_rates)  # the one collective: B*E doubles per rank
+            gather()
 
     def fence():
         torch.cuda.synchronize()
@@ -159,11 +174,11 @@ def main():
         colate_amd.em_batch_device(d_grid, d_sh, d_ns, d_ep, d_init, d_rates, d_iters, d_ll, d_flags)
         ev[k][1].record()
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_rates)
+            gather()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], **f64)
+        t = torch.tensor([elapsed], **f64) if dist.get_backend() == "nccl" else torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
