@@ -105,6 +105,36 @@ def test_em_matches_oracle_122_epochs(ca):
     assert _rel(r1, r0)[mask].max() < RATE_RTOL
 
 
+@pytest.mark.parametrize("bins,E_expect", [("3,7,0.3", 17), ("3,7,0.1", 43), ("3,7,0.07", 61), ("2,7.95,0.03", 202),
+                                           ("2,7.9,0.024", 249)])
+def test_every_kernel_instantiation(ca, bins, E_expect):
+    """The EM kernel is instantiated per epoch-count range (1, 2 or 4 rows of 16 epochs in one chunk of 64;
+    2 and 4 chunks up to 256 epochs): a short EM (same iteration cap on both sides) and one E-step for an epoch
+    count in each range; 17 / 23 / 122 epochs are covered by the other tests."""
+    from colate_amd import workloads
+
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins(bins)
+    assert ep.size == E_expect
+    csh, cns = workloads.bootstrap_tables(grid, 2, nb=9, scale=1.0)
+    kw = dict(max_iter=60, min_iter=20)
+    r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep, **kw)
+    r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep, **kw)
+    assert (it0 == it1).all() and ((fl0 & 3) == 0).all() and (fl0 == fl1).all()
+    assert np.allclose(ll1, ll0, rtol=1e-12, atol=0)
+    mask = ol.stable_mask(grid, csh, cns, ep, r0, **kw)
+    assert mask.mean() > 0.8
+    assert _rel(r1, r0)[mask].max() < RATE_RTOL
+    # one E-step at the rates the EM arrived at
+    num, den, ll, flags = ca.em_estep(grid, csh, cns, ep, r0)
+    for t in range(2):
+        N0, D0, l0, f0 = ol.estep(ep, r0[t], grid, csh[t], cns[t])
+        assert f0 == 0 and flags[t] == 0
+        assert abs(ll[t] - l0) <= 1e-12 * abs(l0)
+        assert _rel(num[t], N0).max() < 1e-8
+        assert (np.abs(den[t] - D0) <= _den_tol(D0, ep, csh[t].sum() + cns[t].sum())).all()
+
+
 def test_coal_EM_mirror_reference_unit_test(ca):
     """Restates TEST_CASE("test EM expectation step") (include/test/test_aDNA.cpp:68-212) with the
     GPU class in place of coal_EM and the oracle in place of coal_EM_simplified, at 1e-9 instead of
