@@ -28,6 +28,9 @@
 // and three workgroup barriers per iteration (epoch values -> bins -> per-epoch
 // sums -> rates).  Per-epoch sums of the per-bin terms are reduced in registers
 // (row-segmented DPP) and handed over through an LDS tile at static "tail" slots.
+// For batches far beyond the CU count the same code is instantiated as a THROUGHPUT
+// variant (template flag TPUT: two waves per replicate that loop over the bin groups;
+// see em_kernel below), with bit-identical results.
 //
 // The reference evaluates exp(log-term - Z) for every (age bin, epoch) pair:
 // O(A*E) transcendentals per iteration.  Here every such term is factored into
@@ -41,6 +44,9 @@
 // uses fma only inside em_math.hpp and in recurrences that have no counterpart
 // in the reference).
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
 
 #include "em_kernels.h"
 #include "em_math.hpp"
@@ -165,14 +171,30 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// what the bin phase (P2) needs to know about one age bin
+struct BinStat {
+  double a_b, cnt, tk, tkn, dtk, da, db;  // age, count (this role's kind), epoch start / end / length, age - start, end - age
+  double f1, f2, f4, f8;                  // 1.0 if the lane 1/2/4/8 to the left (same 16-lane row) is in the same epoch
+  int kb, pos;                            // epoch of the bin; position in the compacted tile
+  bool live, last_bin, is_tail;           // carries data; lies in the last epoch; last lane of its (row, epoch) run
+};
+// packed form of the static part, one int per compacted position (throughput variant)
+enum { BF_F1 = 1, BF_F2 = 2, BF_F4 = 4, BF_F8 = 8, BF_TAIL = 16, BF_INRANGE = 32, BF_KB_SHIFT = 8 };
+
 // MODE 0: EM to convergence, 1: one E-step (num/den/ll out).  NCH = epoch chunks of 64 per lane;
 // EROWS = 16-lane rows of a chunk that hold epochs (1, 2 or 4; 4 whenever NCH > 1).
-template <int MODE, int NCH, int EROWS>
-__global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
+// TPUT = false: the latency variant described at the top (a wave per role and bin group, one workgroup per CU
+// in mind).  TPUT = true: the THROUGHPUT variant for batches far beyond the number of CUs: the same phases and
+// the same arithmetic (results are bit-identical), but one replicate is two waves (one per role) that walk
+// through the bin groups one after the other, their per-bin statics re-read from LDS: a third of the wave
+// slots and fewer registers per replicate, so three times as many replicates are resident per CU and fill
+// the issue slots that a lone workgroup leaves empty at its barriers.
+template <int MODE, int NCH, int EROWS, bool TPUT>
+__global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
   extern __shared__ double lds[];
   const int E = p.E, A = p.A;
   constexpr int EPAD = NCH * kWave;
-  const int NBMAX = blockDim.x >> 7;  // bin groups of 64 the launch provides per role
+  const int NBMAX = (A + kWave - 1) / kWave;  // bin groups of 64 per role
   const int AP = NBMAX * kWave;       // >= A
   const int APZ = AP + 16;            // stride of the per-bin tiles; entries [AP, APZ) stay zero
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -188,9 +210,11 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
   double* s_cfail = s_nd + 4 * EPAD;                 // [2 roles][APZ] counts of bins whose normaliser failed
   double* s_cnt = s_cfail + 2 * APZ;                 // [2 roles][APZ] counts
   double* s_ll = s_cnt + 2 * APZ;                    // [8] per-wave log-likelihood partials
-  int* s_kb = reinterpret_cast<int*>(s_ll + 8);      // [AP + 1] epoch of each bin
+  double* s_age = s_ll + 8;                          // [AP] age grid (throughput variant)
+  int* s_kb = reinterpret_cast<int*>(s_age + AP);    // [AP + 1] epoch of each bin
   int* s_fail = s_kb + AP + 1;                       // [8] per-wave "a bin failed" flags
   int* s_misc = s_fail + 8;                          // [4] nzlo, nzhi, flags
+  int* s_bflags = s_misc + 4;                        // [AP] packed per-position statics (throughput variant)
 
 #ifdef COLATE_EM_TRACE  // diagnostic build (tools/residency_probe.hip): where and when this workgroup ran
   unsigned long long trace_t0;
@@ -210,12 +234,12 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
     s_fail[tid] = 0;
   }
   __syncthreads();
-  if (tid < AP) {
+  for (int t = tid; t < AP; t += blockDim.x) {
     int kb = E;  // padding: beyond every epoch
-    if (tid < A) {
-      const double a = p.age_grid[tid];
-      const double c1 = p.cnt_sh[(size_t)rep * A + tid];
-      const double c2 = p.cnt_ns[(size_t)rep * A + tid];
+    if (t < A) {
+      const double a = p.age_grid[t];
+      const double c1 = p.cnt_sh[(size_t)rep * A + t];
+      const double c2 = p.cnt_ns[(size_t)rep * A + t];
       const double csh = (c1 > 0) ? c1 : 0.0;  // coal.cpp:3706, 3719: only counts > 0 are visited
       const double cns = (c2 > 0) ? c2 : 0.0;
       kb = E - 1;  // coal_EM.cpp:60-95: largest e with epochs[e] <= age (strict `age < epochs[e]`)
@@ -226,14 +250,15 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
         }
       }
       if (kb < 0) kb = 0;  // host validates age >= epochs[0]; never taken
-      s_cnt[tid] = csh;
-      s_cnt[APZ + tid] = cns;
+      s_cnt[t] = csh;
+      s_cnt[APZ + t] = cns;
+      if (TPUT) s_age[t] = a;
       if (csh > 0 || cns > 0) {
-        atomicMin(&s_misc[0], tid);
-        atomicMax(&s_misc[1], tid + 1);
+        atomicMin(&s_misc[0], t);
+        atomicMax(&s_misc[1], t + 1);
       }
     }
-    s_kb[tid] = kb;
+    s_kb[t] = kb;
   }
   if (tid == 0) s_kb[AP] = E + 1;
   __syncthreads();
@@ -299,6 +324,23 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
     if (r >= 8 && s_kb[bin - 8] == kb) f8 = 1.0;
     is_tail = (r == 15) || (bin + 1 >= nzhi) || (s_kb[bin + 1] != kb);
   }
+  const BinStat bs0{a_b, cnt, tk, tkn, dtk, da, db, f1, f2, f4, f8, kb, pos, live, last_bin, is_tail};
+  if (TPUT) {  // the same statics for every compacted position, packed (the bin phase rebuilds a BinStat per group)
+    for (int t = tid; t < AP; t += blockDim.x) {
+      const int b = nzlo + t;
+      int fl = 0;
+      if (t < NB * kWave && b < nzhi) {
+        const int k = s_kb[b], r = t & 15;
+        fl = BF_INRANGE | (k << BF_KB_SHIFT);
+        if (r >= 1 && s_kb[b - 1] == k) fl |= BF_F1;
+        if (r >= 2 && s_kb[b - 2] == k) fl |= BF_F2;
+        if (r >= 4 && s_kb[b - 4] == k) fl |= BF_F4;
+        if (r >= 8 && s_kb[b - 8] == k) fl |= BF_F8;
+        if (r == 15 || b + 1 >= nzhi || s_kb[b + 1] != k) fl |= BF_TAIL;
+      }
+      s_bflags[t] = fl;
+    }
+  }
   // epoch-role statics: where the tails of this epoch sit in the compacted tile, and the counts of
   // the bins in LATER epochs (this role's kind)
   int slot0[NCH], slot1[NCH], slot2[NCH], row_x[NCH], row_hi[NCH], seg_hi[NCH];
@@ -334,7 +376,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
     }
   }
   __syncthreads();
-  if (grp >= NB) return;  // waves without bins retire; later barriers count the remaining waves only
+  if (!TPUT && grp >= NB) return;  // waves without bins retire; later barriers count the remaining waves only
   const bool leader = (grp == 0);
   constexpr int erows = EROWS;  // 16-lane rows that hold epochs: a compile-time constant (skipping the cross-row
                                 // scan steps behind run-time uniform branches measured slower)
@@ -444,7 +486,12 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
     const double lam_last = s_ep[G_LAM * EPAD + E - 1];
     const bool absorbing = lam_last > 0;
     // ============================================================ P2: bin terms (own bins, own role)
-    {
+    auto bin_terms = [&](const BinStat& bs) {
+      const double a_b = bs.a_b, cnt = bs.cnt, tk = bs.tk, tkn = bs.tkn, dtk = bs.dtk, da = bs.da, db = bs.db;
+      const double f1 = bs.f1, f2 = bs.f2, f4 = bs.f4, f8 = bs.f8;
+      const int kb = bs.kb, pos = bs.pos;
+      const bool live = bs.live, last_bin = bs.last_bin, is_tail = bs.is_tail;
+      const int wslot = 2 * (pos >> 6) + role;  // entry of this (bin group, role) in s_fail / s_ll: the latency variant's wave
       double o_w = 0, o_N = 0, o_D = 0, llp = 0.0;
       bool fail = false;
       if (live && !COLATE_ABL_HAS(12)) {
@@ -538,7 +585,11 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
       }
       COLATE_STAMP(1)
       // bins whose normaliser failed (coal_EM.cpp:288-292, 461-465) drop out of the static counts
-      {
+      if (TPUT) {  // (a wave serves several groups: publish every time)
+        s_cfail[role * APZ + pos] = fail ? cnt : 0.0;
+        const bool any_fail = __any(fail);
+        if (lane == 0) s_fail[wslot] = any_fail ? 1 : 0;
+      } else {
         const bool any_fail = __any(fail);
         if (fail || wrote_fail) {  // publish, or clear what this lane published last time
           COLATE_COLD();
@@ -547,7 +598,7 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
         wrote_fail = fail;
         if (any_fail != flag_set) {  // (uniform) publish the per-wave flag only when it changes
           COLATE_COLD();
-          if (lane == 0) s_fail[wave] = any_fail ? 1 : 0;
+          if (lane == 0) s_fail[wslot] = any_fail ? 1 : 0;
           flag_set = any_fail;
         }
       }
@@ -571,8 +622,34 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
       if (need_ll) {
         COLATE_COLD();
         const double tot = readlane_d(wave_prefix_sum(llp), 63);
-        if (lane == 0) s_ll[wave] = tot;
+        if (lane == 0) s_ll[wslot] = tot;
       }
+    };
+    if (TPUT) {
+      for (int g = 0; g < NB; g++) {  // this role's bin groups, one after the other
+        const int gpos = g * kWave + lane, fl = s_bflags[gpos], gbin = nzlo + gpos;
+        const bool inr = fl & BF_INRANGE;
+        BinStat b;
+        b.kb = inr ? (fl >> BF_KB_SHIFT) : 0;
+        b.pos = gpos;
+        b.a_b = inr ? s_age[gbin] : 0.0;
+        b.cnt = inr ? s_cnt[role * APZ + gbin] : 0.0;
+        b.tk = s_t[b.kb];
+        b.tkn = (b.kb < E - 1) ? s_t[b.kb + 1] : 0.0;
+        b.dtk = (b.kb < E - 1) ? b.tkn - b.tk : 0.0;
+        b.da = b.a_b - b.tk;
+        b.db = b.tkn - b.a_b;
+        b.f1 = (fl & BF_F1) ? 1.0 : 0.0;
+        b.f2 = (fl & BF_F2) ? 1.0 : 0.0;
+        b.f4 = (fl & BF_F4) ? 1.0 : 0.0;
+        b.f8 = (fl & BF_F8) ? 1.0 : 0.0;
+        b.live = inr && b.cnt > 0;
+        b.last_bin = (b.kb == E - 1);
+        b.is_tail = fl & BF_TAIL;
+        bin_terms(b);
+      }
+    } else {
+      bin_terms(bs0);
     }
     COLATE_STAMP(2)
     __syncthreads();  // ---- barrier 2: per-bin tails visible
@@ -835,9 +912,9 @@ __global__ __launch_bounds__(2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p)
   }
 }
 
-template <int MODE, int NCH, int EROWS>
+template <int MODE, int NCH, int EROWS, bool TPUT>
 hipError_t launch_one(const ColateEmArgs& args, hipStream_t stream, size_t lds, int threads) {
-  auto kern = em_kernel<MODE, NCH, EROWS>;
+  auto kern = em_kernel<MODE, NCH, EROWS, TPUT>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -850,16 +927,41 @@ hipError_t launch_one(const ColateEmArgs& args, hipStream_t stream, size_t lds, 
 }  // namespace
 
 static int em_groups(int A) { return (A + 63) / 64; }           // bin groups of 64 per role
-static int em_threads(int A) { return 2 * 64 * em_groups(A); }  // two roles
+static int em_threads(int A) { return 2 * 64 * em_groups(A); }  // two roles (latency variant)
 static int em_chunks(int E) { return E <= 64 ? 1 : (E <= 128 ? 2 : 4); }
 
 size_t colate_em_lds_bytes(int E, int A) {
   const size_t EPAD = (size_t)em_chunks(E) * kWave;
   const size_t AP = (size_t)em_groups(A) * kWave;
   const size_t APZ = AP + 16;
-  const size_t doubles = (EPAD + 1) + kNumGather * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ + 8;
-  const size_t ints = (AP + 1) + 8 + 4;
+  const size_t doubles = (EPAD + 1) + kNumGather * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ + 8 + AP;
+  const size_t ints = (AP + 1) + 8 + 4 + AP;
   return doubles * sizeof(double) + ints * sizeof(int);
+}
+
+// number of CUs of the current device (cached per ordinal)
+static int device_cus() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = -1;
+    cus[dev] = n;
+  }
+  return cus[dev] > 0 ? cus[dev] : 0;
+}
+
+// The throughput variant pays off once the latency variant would leave workgroups waiting for a CU (it holds
+// two per CU).  COLATE_EM_VARIANT=latency|throughput overrides the choice (tests, experiments).
+static bool use_throughput_variant(const ColateEmArgs& args) {
+  if (args.mode != 0 || em_chunks(args.E) > 2) return false;
+  if (const char* v = getenv("COLATE_EM_VARIANT")) {
+    if (!strcmp(v, "throughput")) return true;
+    if (!strcmp(v, "latency")) return false;
+  }
+  const int cus = device_cus();
+  return cus > 0 && args.B > 2 * cus;
 }
 
 hipError_t colate_em_launch(const ColateEmArgs& args, hipStream_t stream) {
@@ -868,15 +970,21 @@ hipError_t colate_em_launch(const ColateEmArgs& args, hipStream_t stream) {
   const int nch = em_chunks(args.E);
   const int rows = args.E <= 16 ? 1 : (args.E <= 32 ? 2 : 4);  // BASELINE's `--bins 3,7,0.2` gives E = 23
   if (args.mode == 1) {
-    if (nch == 1) return launch_one<1, 1, 4>(args, stream, lds, threads);
-    if (nch == 2) return launch_one<1, 2, 4>(args, stream, lds, threads);
-    return launch_one<1, 4, 4>(args, stream, lds, threads);
+    if (nch == 1) return launch_one<1, 1, 4, false>(args, stream, lds, threads);
+    if (nch == 2) return launch_one<1, 2, 4, false>(args, stream, lds, threads);
+    return launch_one<1, 4, 4, false>(args, stream, lds, threads);
+  }
+  if (use_throughput_variant(args)) {
+    if (nch == 2) return launch_one<0, 2, 4, true>(args, stream, lds, 2 * kWave);
+    if (rows == 1) return launch_one<0, 1, 1, true>(args, stream, lds, 2 * kWave);
+    if (rows == 2) return launch_one<0, 1, 2, true>(args, stream, lds, 2 * kWave);
+    return launch_one<0, 1, 4, true>(args, stream, lds, 2 * kWave);
   }
   if (nch == 1) {
-    if (rows == 1) return launch_one<0, 1, 1>(args, stream, lds, threads);
-    if (rows == 2) return launch_one<0, 1, 2>(args, stream, lds, threads);
-    return launch_one<0, 1, 4>(args, stream, lds, threads);
+    if (rows == 1) return launch_one<0, 1, 1, false>(args, stream, lds, threads);
+    if (rows == 2) return launch_one<0, 1, 2, false>(args, stream, lds, threads);
+    return launch_one<0, 1, 4, false>(args, stream, lds, threads);
   }
-  if (nch == 2) return launch_one<0, 2, 4>(args, stream, lds, threads);
-  return launch_one<0, 4, 4>(args, stream, lds, threads);
+  if (nch == 2) return launch_one<0, 2, 4, false>(args, stream, lds, threads);
+  return launch_one<0, 4, 4, false>(args, stream, lds, threads);
 }

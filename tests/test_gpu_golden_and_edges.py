@@ -225,6 +225,35 @@ def test_sharded_entry_point_matches_single_launch(ca):
         ca.em_batch_sharded([99], grid, csh, cns, ep)
 
 
+def test_throughput_variant_is_bit_identical(ca, monkeypatch):
+    """The kernel has a latency variant (a wave per role and bin group; B up to twice the CU count) and a
+    throughput variant (two waves per replicate walking through the bin groups; larger B).  Same phases, same
+    arithmetic: rates, log-likelihoods, iteration counts and flags agree bit for bit, so results do not depend
+    on the batch size a replicate happens to be run in."""
+    from colate_amd import workloads
+
+    grid = ol.age_grid()
+    for bins, nrep in (("3,7,0.2", 12), ("2,7.95,0.05", 3), ("3,7,0.3", 3)):
+        ep, _ = ol.epochs_from_bins(bins)
+        csh, cns = workloads.bootstrap_tables(grid, nrep, nb=9, scale=1.0)
+        csh[0, :] = 0.0          # a replicate without shared counts
+        cns[1, 60:] = 0.0        # one whose data stop early (one bin group)
+        out = {}
+        for variant in ("latency", "throughput"):
+            monkeypatch.setenv("COLATE_EM_VARIANT", variant)
+            out[variant] = ca.em_batch(grid, csh, cns, ep)
+        for a, b in zip(out["latency"], out["throughput"]):
+            assert np.array_equal(a, b)
+    monkeypatch.delenv("COLATE_EM_VARIANT")
+    # the library picks the throughput variant by itself for a batch beyond 2 x #CUs: spot-check against the oracle
+    ep, _ = ol.epochs_from_bins("3,7,0.2")
+    csh, cns = workloads.bootstrap_tables(grid, 600, nb=115, scale=11.0, seed=3)
+    r, it, ll, fl = ca.em_batch(grid, csh, cns, ep)
+    idx = [0, 299, 599]
+    r0, it0, ll0, _ = ol.em_batch(grid, csh[idx], cns[idx], ep)
+    assert (fl == 0).all() and (it[idx] == it0).all() and _rel(r[idx], r0).max() < 1e-8
+
+
 def test_rows_sharded_entry_point_matches_rows_launch(ca):
     """colate_em_batch_rows_sharded: per-row epochs (batched pairs) sharded over devices/streams; rows come
     back in order, bit-identical to colate_em_batch_rows."""
