@@ -81,20 +81,20 @@ constexpr int ROW_BCAST15 = 0x142, ROW_BCAST31 = 0x143, WAVE_SHR1 = 0x138, WAVE_
 
 // inclusive prefix sum over the lanes of the first `rows` rows
 __device__ __forceinline__ double wave_prefix_sum(double v, int rows = 4) {
-  v += dpp_d<ROW_SHR1>(0.0, v);
-  v += dpp_d<ROW_SHR2>(0.0, v);
-  v += dpp_d<ROW_SHR4>(0.0, v);
-  v += dpp_d<ROW_SHR8>(0.0, v);
+  v += dpp_d<ROW_SHR1, 0xf, true>(0.0, v);
+  v += dpp_d<ROW_SHR2, 0xf, true>(0.0, v);
+  v += dpp_d<ROW_SHR4, 0xf, true>(0.0, v);
+  v += dpp_d<ROW_SHR8, 0xf, true>(0.0, v);
   if (rows > 1) v += dpp_d<ROW_BCAST15, 0xa>(0.0, v);
   if (rows > 2) v += dpp_d<ROW_BCAST31, 0xc>(0.0, v);
   return v;
 }
 // inclusive suffix sum (lane l: sum of lanes l..), lanes beyond the rows in use must hold 0
 __device__ __forceinline__ double wave_suffix_sum(double v, int lane, int rows = 4) {
-  v += dpp_d<ROW_SHL1>(0.0, v);
-  v += dpp_d<ROW_SHL2>(0.0, v);
-  v += dpp_d<ROW_SHL4>(0.0, v);
-  v += dpp_d<ROW_SHL8>(0.0, v);
+  v += dpp_d<ROW_SHL1, 0xf, true>(0.0, v);
+  v += dpp_d<ROW_SHL2, 0xf, true>(0.0, v);
+  v += dpp_d<ROW_SHL4, 0xf, true>(0.0, v);
+  v += dpp_d<ROW_SHL8, 0xf, true>(0.0, v);
   if (rows > 1) {
     const double r1 = readlane_d(v, 16);
     double add = 0.0;
@@ -113,19 +113,19 @@ __device__ __forceinline__ double wave_suffix_sum(double v, int lane, int rows =
 // inclusive prefix composition of the affine maps x -> a*x + b (lane order = application order):
 // afterwards (a, b) of lane l is f_l o ... o f_0
 __device__ __forceinline__ void wave_affine_scan(double& a, double& b, int rows = 4) {
-#define COLATE_AFF_STEP(CTRL, RM)                  \
+#define COLATE_AFF_STEP(CTRL, RM, BND)             \
   {                                                \
     const double as = dpp_d<CTRL, RM>(1.0, a);     \
-    const double bs = dpp_d<CTRL, RM>(0.0, b);     \
+    const double bs = dpp_d<CTRL, RM, BND>(0.0, b); \
     b = em::fma_(a, bs, b);                        \
     a = a * as;                                    \
   }
-  COLATE_AFF_STEP(ROW_SHR1, 0xf)
-  COLATE_AFF_STEP(ROW_SHR2, 0xf)
-  COLATE_AFF_STEP(ROW_SHR4, 0xf)
-  COLATE_AFF_STEP(ROW_SHR8, 0xf)
-  if (rows > 1) COLATE_AFF_STEP(ROW_BCAST15, 0xa)
-  if (rows > 2) COLATE_AFF_STEP(ROW_BCAST31, 0xc)
+  COLATE_AFF_STEP(ROW_SHR1, 0xf, true)
+  COLATE_AFF_STEP(ROW_SHR2, 0xf, true)
+  COLATE_AFF_STEP(ROW_SHR4, 0xf, true)
+  COLATE_AFF_STEP(ROW_SHR8, 0xf, true)
+  if (rows > 1) COLATE_AFF_STEP(ROW_BCAST15, 0xa, false)
+  if (rows > 2) COLATE_AFF_STEP(ROW_BCAST31, 0xc, false)
 #undef COLATE_AFF_STEP
 }
 

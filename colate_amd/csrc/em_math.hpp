@@ -27,6 +27,31 @@ namespace em {
 
 EM_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// c1 * x + c0 with two CONSTANTS.  On gfx950 the compiler selects the two-address v_fmac_f64 and then
+// copies c0 into the destination first (one v_mov_b64 per term: c0 stays live across the EM loop); spelling
+// the three-address v_fma_f64 out -- c1 from a scalar register pair, c0 from a loop-invariant vector pair --
+// drops those copies from the dependent chains of the kernel.  Same operation, same result.
+EM_HD double fma_cc(double c1, double x, double c0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "s"(c1), "v"(x), "v"(c0));
+  return d;
+#else
+  return __builtin_fma(c1, x, c0);
+#endif
+}
+// max(x, lo) for a constant lo and a non-NaN x: one v_max_f64 (the builtin adds a canonicalising
+// v_max_f64 x, x in front of it under IEEE mode).  Host: fmax.
+EM_HD double max_c(double x, double lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double d;
+  asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(x), "s"(lo));
+  return d;
+#else
+  return __builtin_fmax(x, lo);
+#endif
+}
+
 // Core of exp(): for xc >= -1100 returns y and k with exp(xc) = y * 2^k, y in [0.70, 1.42), and the
 // pieces (rh, tp) of exp(rh) - 1 = rh + tp that 1 - exp() needs near 0.  The polynomial is
 // evaluated Estrin-style (depth 5 instead of 12: the EM kernel is a chain of dependent
@@ -55,12 +80,12 @@ EM_HD ExpParts em_exp_parts(double xc) {
   const double r2 = rh * rh;
   const double r4 = r2 * r2;
   const double r8 = r4 * r4;
-  const double a0 = fma_(0x1.5555555555555p-5, rh, 0x1.5555555555555p-3);    // 1/3! + r/4!
-  const double a1 = fma_(0x1.6c16c16c16c17p-10, rh, 0x1.1111111111111p-7);   // 1/5! + r/6!
-  const double a2 = fma_(0x1.a01a01a01a01ap-16, rh, 0x1.a01a01a01a01ap-13);  // 1/7! + r/8!
-  const double a3 = fma_(0x1.27e4fb7789f5cp-22, rh, 0x1.71de3a556c734p-19);  // 1/9! + r/10!
-  const double a4 = fma_(0x1.1eed8eff8d898p-29, rh, 0x1.ae64567f544e4p-26);  // 1/11! + r/12!
-  const double a5 = fma_(0x1.93974a8c07c9dp-37, rh, 0x1.6124613a86d09p-33);  // 1/13! + r/14!
+  const double a0 = fma_cc(0x1.5555555555555p-5, rh, 0x1.5555555555555p-3);    // 1/3! + r/4!
+  const double a1 = fma_cc(0x1.6c16c16c16c17p-10, rh, 0x1.1111111111111p-7);   // 1/5! + r/6!
+  const double a2 = fma_cc(0x1.a01a01a01a01ap-16, rh, 0x1.a01a01a01a01ap-13);  // 1/7! + r/8!
+  const double a3 = fma_cc(0x1.27e4fb7789f5cp-22, rh, 0x1.71de3a556c734p-19);  // 1/9! + r/10!
+  const double a4 = fma_cc(0x1.1eed8eff8d898p-29, rh, 0x1.ae64567f544e4p-26);  // 1/11! + r/12!
+  const double a5 = fma_cc(0x1.93974a8c07c9dp-37, rh, 0x1.6124613a86d09p-33);  // 1/13! + r/14!
   const double b0 = fma_(a1, r2, a0);
   const double b1 = fma_(a3, r2, a2);
   const double b2 = fma_(a5, r2, a4);
@@ -79,14 +104,14 @@ EM_HD ExpParts em_exp_parts(double xc) {
 // arguments underflow gradually to 0 through ldexp.  A NaN argument is NOT propagated (fmax drops it:
 // the result is exp(-1100) = 0); the kernel's arguments are sums of finite products.
 EM_HD double em_exp(double x) {
-  const double xc = __builtin_fmax(x, -1100.0);  // keeps k in range; exp(-1100) == 0 anyway
+  const double xc = max_c(x, -1100.0);  // keeps k in range; exp(-1100) == 0 anyway
   const ExpParts o = em_exp_parts(xc);
   return __builtin_ldexp(o.y, o.ki);
 }
 
 // exp(x) and 1 - exp(x) for x <= 0, the latter without cancellation near 0 (|error| <= ~1 ulp).
 EM_HD double em_exp_om(double x, double* one_minus) {
-  const double xc = __builtin_fmax(x, -1100.0);
+  const double xc = max_c(x, -1100.0);
   const ExpParts o = em_exp_parts(xc);
   const double y = __builtin_ldexp(o.y, o.ki);
   *one_minus = (o.ki == 0) ? -(o.rh + o.tp) : 1.0 - y;
