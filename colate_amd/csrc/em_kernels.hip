@@ -345,6 +345,19 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   // the bins in LATER epochs (this role's kind)
   int slot0[NCH], slot1[NCH], slot2[NCH], row_x[NCH], row_hi[NCH], seg_hi[NCH];
   double C0[NCH];
+  // The reference's denominators contain dt_e * integ with integ = 1 - num[0] - num[1] - ... (coal_EM.cpp:270-274,
+  // 445-449): where the mass still to coalesce is below the resolution of that subtraction (survival < ~1e-16:
+  // epochs behind a very high rate, or far older than all data) what remains is its rounding residue, which is
+  // >= 0 after the reference's clamps and averages kIntegResidue per unit count (measured on the reference:
+  // 2.7e-17 .. 5.7e-17, i.e. ~0.36 * 2^-53).  That residue is what drives the reference's rate to its floor in such
+  // epochs.  The factored sums below are exact there (mass 0), so the residue is put in explicitly: without it
+  // those epochs would get the ratio of two vanishing numbers instead of the reference's floor.
+  constexpr double kIntegResidue = 4.0e-17;
+  double c_all = 0.0;
+  for (int b = 0; b < A; b++) c_all += s_cnt[role * APZ + b];
+  double eta_e[NCH];  // dt_e * residue of this role's bins (0 in the last epoch, which has no dt_e * integ term)
+#pragma unroll
+  for (int c = 0; c < NCH; c++) eta_e[c] = dt_e[c] * (kIntegResidue * c_all);
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
     const int e = c * kWave + lane;
@@ -675,7 +688,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         }
         w[c] = (w0 + w1) + w2;
         oN[c] = (n0 + n1) + n2;
-        oD[c] = (d0 + d1) + d2;
+        oD[c] = ((d0 + d1) + d2) + eta_e[c];  // (the residue joins the own-epoch sum: off the scan's dependency chain)
         for (int r = row_x[c]; r <= row_hi[c]; r++) {
           COLATE_COLD();
           int slot = r * 16 + 15;

@@ -31,3 +31,19 @@ def bootstrap_tables(age_grid, B, nb=115, scale=11.0, ne2=12000.0, seed=12345):
     else:
         W = rng.multinomial(nb, np.full(nb, 1.0 / nb), size=B).astype(np.float64)
     return W @ sh_b, W @ ns_b
+
+
+def sparse_tables(age_grid, B, seed=None):
+    """Low-coverage-like tables: per replicate a Poisson number of mutations per age bin (mean 0.3 .. 30, bins
+    35..159) split binomially into shared / not shared with p = 0.8 (1 - exp(-age / Ne2)), Ne2 ~ U(3000, 40000).
+    Convergence is slow and irregular (1001 .. 70000 iterations), single epochs get very high rates, and the
+    epochs behind them fall below the resolution of the reference's `integ`: the inputs of
+    tools/parity_sweep.py and of the tests of that regime."""
+    rng = np.random.default_rng(B if seed is None else seed)
+    A = age_grid.size
+    tot = rng.poisson(np.exp(rng.uniform(np.log(0.3), np.log(30), (B, 1))) * np.ones((1, A))).astype(float)
+    tot[:, :35] = 0
+    tot[:, 160:] = 0
+    p = 1 - np.exp(-age_grid / rng.uniform(3000, 40000, (B, 1)))
+    csh = rng.binomial(tot.astype(int), np.clip(0.8 * p, 0, 1)).astype(float)
+    return csh, tot - csh

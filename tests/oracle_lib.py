@@ -125,4 +125,9 @@ def stable_mask(grid, csh, cns, epochs, rates0, rtol=1e-8, **kw):
     r1, _, _, _ = em_batch(grid, s * (1 + 2.0 ** -52), n * (1 + 2.0 ** -52), epochs, **kw)
     r2, _, _, _ = em_batch(grid, s * (1 - 2.0 ** -53), n * (1 - 2.0 ** -53), epochs, **kw)
     den = np.maximum(np.abs(rates0), 1e-300)
-    return (np.abs(r1 - rates0) / den < rtol) & (np.abs(r2 - rates0) / den < rtol)
+    stable = (np.abs(r1 - rates0) / den < rtol) & (np.abs(r2 - rates0) / den < rtol)
+    # An epoch older than an unresolved one inherits it: its survival probability is a product over the younger
+    # epochs' rates, and the EM couples them iteration after iteration (seen with sparse tables, where a noise-
+    # determined rate is followed by epochs that read "floor" in one run and 1e-6 in another implementation).
+    # So only epochs with nothing unresolved before them count.
+    return np.logical_and.accumulate(stable, axis=1)

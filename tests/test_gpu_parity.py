@@ -135,6 +135,34 @@ def test_every_kernel_instantiation(ca, bins, E_expect):
         assert (np.abs(den[t] - D0) <= _den_tol(D0, ep, csh[t].sum() + cns[t].sum())).all()
 
 
+def test_sparse_tables_and_the_integ_residue(ca):
+    """Low-coverage-like tables (a few mutations per age bin): irregular convergence, single epochs with very
+    high rates, and behind them epochs whose survival probability is below the resolution of the reference's
+    `integ = 1 - num[0] - ...`: there the reference's denominator is the rounding residue of that subtraction and
+    its rate drops to the floor.  The kernel reproduces the residue explicitly (em_kernels.hip, kIntegResidue):
+    same iteration counts, rates within 1e-6 on every resolved epoch, the floor where the reference has it."""
+    from colate_amd import workloads
+
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins("3,7,0.2")
+    csh, cns = workloads.sparse_tables(grid, 512)
+    idx = [97, 178, 246, 286, 352, 3, 400]  # the first five have epochs behind a rate spike (cumsum > 45)
+    csh, cns = csh[idx], cns[idx]
+    r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep)
+    r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep)
+    assert ((fl0 & 3) == 0).all() and (fl1 == fl0).all()
+    assert (it0 == it1).all() and it0.max() > 1001
+    assert np.allclose(ll1, ll0, rtol=1e-11, atol=0)
+    mask = ol.stable_mask(grid, csh, cns, ep, r0)
+    assert mask.mean() > 0.9
+    assert _rel(r1, r0)[mask].max() < RATE_RTOL
+    # the regime is really there: resolved epochs at the floor right behind a rate above 1e-3, in several replicates
+    floor_behind_spike = [(r0[b, 1:] == 5e-9) & mask[b, 1:] & (np.maximum.accumulate(r0[b, :-1]) > 1e-3) for b in range(len(idx))]
+    assert sum(f.any() for f in floor_behind_spike) >= 3
+    for b, f in enumerate(floor_behind_spike):
+        assert (r1[b, 1:][f] == 5e-9).all()
+
+
 def test_coal_EM_mirror_reference_unit_test(ca):
     """Restates TEST_CASE("test EM expectation step") (include/test/test_aDNA.cpp:68-212) with the
     GPU class in place of coal_EM and the oracle in place of coal_EM_simplified, at 1e-9 instead of
