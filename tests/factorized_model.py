@@ -13,6 +13,9 @@ oracle/ on the CPU (tests/test_factorized_model.py) without a GPU.
 import numpy as np
 
 
+INTEG_RESIDUE = 4.0e-17  # per unit count
+
+
 def epoch_index(age_grid, epochs):
     """k(a) = largest e with epochs[e] <= a  (coal_EM.cpp:66 strict `age < epochs[e]`)."""
     return np.searchsorted(epochs, age_grid, side="right") - 1
@@ -132,6 +135,8 @@ def estep(epochs, rates, age_grid, c_sh, c_ns):
                 D[e] = (VW[e] * rs + dt[e] * (cs_ - PW[e + 1] * rs) + gV[e]
                         + dt[e] * cn + (beta[e] - t[e] * p[e]) * T[e]
                         + dt[e] * G[e + 1] * (q[e] * T[e]) + hD[e])
+                # the rounding residue of the reference's `integ` (em_kernels.hip kIntegResidue)
+                D[e] += dt[e] * (INTEG_RESIDUE * (c_sh.sum() + c_ns.sum()))
             else:
                 D[e] = gV[e] + (beta[e] - t[e] * p[e]) * T[e] + hD[e]
     return N, D, ll
