@@ -126,6 +126,17 @@ def stable_mask(grid, csh, cns, epochs, rates0, rtol=1e-8, **kw):
     r2, _, _, _ = em_batch(grid, s * (1 - 2.0 ** -53), n * (1 - 2.0 ** -53), epochs, **kw)
     den = np.maximum(np.abs(rates0), 1e-300)
     stable = (np.abs(r1 - rates0) / den < rtol) & (np.abs(r2 - rates0) / den < rtol)
+    # ... and whose denominator, in the reference's own E-step at its final rates, is either at least 1e7 times the
+    # rounding residue of `integ` (~4e-17 per unit count and unit epoch length, DESIGN.md §6: what the reference
+    # adds there is known to +-50 % only) or nothing but that residue (ratio < 3: the rate is the floor).
+    ep = f64(epochs)
+    dt = np.append(np.diff(ep), 0.0)
+    for b in range(s.shape[0]):
+        _, D0, _, _ = estep(ep, rates0[b], grid, s[b], n[b])
+        residue = dt * 4e-17 * (s[b].sum() + n[b].sum())
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rho = np.where(residue > 0, D0 / residue, np.inf)
+        stable[b] &= (rho > 1e7) | ((rho < 3) & (rates0[b] <= 5e-9))
     # An epoch older than an unresolved one inherits it: its survival probability is a product over the younger
     # epochs' rates, and the EM couples them iteration after iteration (seen with sparse tables, where a noise-
     # determined rate is followed by epochs that read "floor" in one run and 1e-6 in another implementation).

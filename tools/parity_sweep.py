@@ -3,7 +3,9 @@
 (tests/oracle_lib: the C restatement, in worker processes); reports iteration-count mismatches and the largest
 relative rate difference over the epochs whose oracle value is stable (oracle_lib.stable_mask).
 
-    python tools/parity_sweep.py [replicates] [scale] [bins]
+    python tools/parity_sweep.py [replicates] [scale] [bins] [sample_age_in_years]
+(scale <= 0: sparse low-coverage-like tables; a sample age > 0 builds the epochs as for an ancient sample and
+removes the counts of the age bins younger than it)
 """
 import os
 import sys
@@ -34,11 +36,15 @@ def main():
     scale = float(sys.argv[2]) if len(sys.argv) > 2 else 11.0
     bins = sys.argv[3] if len(sys.argv) > 3 else "3,7,0.2"
     grid = ol.age_grid()
-    ep, _ = ol.epochs_from_bins(bins)
+    age = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+    ep, _ = ol.epochs_from_bins(bins, age, 28.0)
     if scale > 0:
         csh, cns = workloads.bootstrap_tables(grid, B, nb=115 if scale > 2 else 9, scale=scale, seed=int(scale * 100) + B)
     else:  # scale <= 0: sparse, noisy tables (few mutations per bin): slow, irregular convergence
         csh, cns = workloads.sparse_tables(grid, B)
+    if age > 0:
+        csh[:, grid < age / 28.0] = 0.0
+        cns[:, grid < age / 28.0] = 0.0
     t = time.time()
     r1, it1, ll1, fl1 = colate_amd.em_batch(grid, csh, cns, ep)
     print(f"GPU: {B} replicates in {time.time() - t:.3f} s (incl. transfers), flags nonzero: {(fl1 != 0).sum()}", flush=True)
