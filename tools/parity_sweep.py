@@ -3,7 +3,7 @@
 (tests/oracle_lib: the C restatement, in worker processes); reports iteration-count mismatches and the largest
 relative rate difference over the epochs whose oracle value is stable (oracle_lib.stable_mask).
 
-    python tools/parity_sweep.py [replicates] [scale] [bins] [sample_age_in_years]
+    python tools/parity_sweep.py [replicates] [scale] [bins] [sample_age_in_years] [Ne2 of the dense tables]
 (scale <= 0: sparse low-coverage-like tables; a sample age > 0 builds the epochs as for an ancient sample and
 removes the counts of the age bins younger than it)
 """
@@ -39,7 +39,8 @@ def main():
     age = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
     ep, _ = ol.epochs_from_bins(bins, age, 28.0)
     if scale > 0:
-        csh, cns = workloads.bootstrap_tables(grid, B, nb=115 if scale > 2 else 9, scale=scale, seed=int(scale * 100) + B)
+        ne2 = float(sys.argv[5]) if len(sys.argv) > 5 else 12000.0
+        csh, cns = workloads.bootstrap_tables(grid, B, nb=115 if scale > 2 else 9, scale=scale, ne2=ne2, seed=int(scale * 100) + B)
     else:  # scale <= 0: sparse, noisy tables (few mutations per bin): slow, irregular convergence
         csh, cns = workloads.sparse_tables(grid, B)
     if age > 0:
