@@ -84,6 +84,20 @@ def test_epochs_23_and_122(ca):
     assert ca.epochs_from_bins("2,7.95,0.05")[0].size == 122  # configs[3] (2,8,0.05 aborts the reference)
 
 
+def test_bins_2_8_005_is_rejected_like_the_reference_aborts(ca):
+    """BASELINE configs[3] as written, `--bins 2,8,0.05`: the float-accumulated start of the last regular epoch,
+    exp(ln10 * 8)/28 = 3571428.571428578, exceeds the hard-coded final epoch 1e8/28 (coal.cpp:3628-3629) and the
+    reference aborts at coal_EM.cpp:114 (assert t_end >= t_begin).  Here the epoch builder returns the same
+    (decreasing) grid and every EM entry point refuses it -- before touching a device."""
+    ep, _ = ca.epochs_from_bins("2,8,0.05")
+    assert ep.size == 123 and ep[-1] < ep[-2]
+    grid = ca.age_grid()
+    z = np.zeros((1, grid.size))
+    with pytest.raises(ca.ColateError) as e:
+        ca.em_batch(grid, z + 1.0, z + 1.0, ep)
+    assert e.value.code == -1 and "non-decreasing" in str(e.value)
+
+
 def test_block_bootstrap_matches_oracle_and_restated_rng(ca):
     """std::mt19937 + uniform_int_distribution in the product vs the oracle's restatement of both
     (Matsumoto-Nishimura + libstdc++-11 Lemire), then the weighted sums and the F redistribution."""
