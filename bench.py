@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- bootstrap replicates / second to EM convergence on MI355X.
 
-A "step" is one pass of the hot path over one batch: B bootstrap replicates (count tables
-already resident in HBM) run to the reference's stop rule (coal.cpp:3822) by ONE launch of the
-EM kernel through the C ABI (colate_em_batch_device), followed -- when N > 1 -- by the single
-RCCL all-gather of the rates.  Workload = BASELINE.json configs[1]: whole-genome-like counts,
-num_bootstrap = 100 per GPU, --bins 3,7,0.2 (23 epochs), 185 age bins (synthetic: the SGDP /
-LBK / Loschbour files are not available offline; colate_amd/workloads.py).
+A "step" is one pass of the hot path over one batch, from "count tables resident in HBM" to "rates gathered on
+the host" (SURVEY.md section 8d): ONE launch of the EM kernel through the C ABI (colate_em_batch_device) runs
+this rank's bootstrap replicates to the reference's stop rule (coal.cpp:3822); when N > 1 the single RCCL
+all-gather of the packed results follows (colate_amd/distributed.py: the code the gloo test covers); then one
+device-to-host copy of the results and a stream synchronisation.  All of that is inside the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Workload = BASELINE.json configs[1]: whole-genome-like counts, num_bootstrap = 100 per GPU, --bins 3,7,0.2
+(23 epochs), 185 age bins (synthetic: the SGDP / LBK / Loschbour files are not available offline;
+colate_amd/workloads.py).  `--total-replicates 1000` is configs[2] as written: 1000 replicates sharded over
+the N GPUs (strong scaling) instead of 100 per GPU (weak scaling, the default).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the EM kernel against HBM as SURVEY.md §8(d)
-prescribes (algorithmic bytes per replicate-iteration = 2*A*8 counts + A*8 grid + 3*E*8
-epochs/rates); `cpu_baseline` times the reference itself (oracle/_ref/Colate_ref, built from
-/root/reference by oracle/Makefile) -- or, if that binary did not travel, our C restatement
+    python bench.py [--gpus N] [--steps K] [--warmup W]           (N > 1: spawns N rank processes itself)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (also fine)
+
+Rank 0 prints ONE JSON line.  `roofline` prices the EM kernel against HBM as SURVEY.md section 8(d) prescribes
+(algorithmic bytes per replicate-iteration = 2*A*8 counts + A*8 grid + 3*E*8 epochs/rates) and names what
+really bounds it (`roofline.latency`); `cpu_baseline` times the reference itself (oracle/_ref/Colate_ref, built
+from /root/reference by oracle/Makefile) -- or, if that binary did not travel, our C restatement
 (oracle/liboracle.so) -- on one host core over a bounded sample of the same replicates.
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -31,38 +36,90 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PEAK_CLOCK_HZ = 2.4e9  # same guide: max clock
 BINS = "3,7,0.2"
 B_PER_GPU = 100
-CPU_SAMPLE = 64  # replicates timed on the host (about 10 s on one core)
+CPU_SAMPLE = 64  # replicates timed on the host (about 10 s on one core at 23 epochs)
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--replicates", type=int, default=B_PER_GPU, help="bootstrap replicates per GPU (weak scaling)")
+    ap.add_argument("--total-replicates", type=int, default=0,
+                    help="strong scaling: this many replicates in total, sharded over the GPUs (BASELINE configs[2]: 1000)")
+    ap.add_argument("--bins", default=BINS, help="epoch grid (default: the BASELINE config; 2,7.95,0.05 = 122 epochs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive (host-pointer ABI) timing")
+    ap.add_argument("--no-cxx-rccl-check", action="store_true",
+                    help="skip the run of `Colate --ranks N` (C++ host + RCCL all-gather) after the measurement")
+    return ap.parse_args()
+
+
+# --------------------------------------------------------------------------------------------- launcher
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh rank processes (this process
+    never touches a GPU) with the environment torch.distributed.run would give them; rank 0 inherits stdout."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = None if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rc = 0
+    pending = set(range(n))
+    failed_at = None
+    while pending:
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    failed_at = failed_at or time.time()
+        if failed_at and pending and time.time() - failed_at > 15:  # a rank died: do not leave the others in a collective
+            for r in pending:
+                procs[r].kill()
+        time.sleep(0.2)
+    return rc
+
+
+# --------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(grid, csh, cns, epochs, gpu_rates, gpu_iters, bins=BINS):
     """Time the CPU path on `CPU_SAMPLE` of the benchmark's replicates, one core."""
-    S = min(CPU_SAMPLE, csh.shape[0])
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "Colate_ref")
     E = epochs.size
+    S = min(CPU_SAMPLE if E <= 64 else CPU_SAMPLE // 4, csh.shape[0])
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "Colate_ref")
     if os.path.exists(ref_bin) and os.access(ref_bin, os.X_OK):
         with tempfile.TemporaryDirectory() as d:
             # the reference's own hook for precomputed count tables (coal.cpp:3169-3170, 3471-3499)
-            with open(os.path.join(d, "OUT.colate_mat"), "w") as f:
-                f.write(" ".join("%.17g" % x for x in grid) + "\n")
-                for b in range(S):
-                    f.write(" ".join("%.17g" % x for x in csh[b]) + "\n")
-                    f.write(" ".join("%.17g" % x for x in cns[b]) + "\n")
+            write_colate_mat(os.path.join(d, "OUT.colate_mat"), grid, csh[:S], cns[:S])
             cmd = [ref_bin, "--mode", "mut", "--mut", "dummy", "--bins", bins, "--num_bootstraps", str(S), "-o", "OUT"]
             t0 = time.perf_counter()
             r = subprocess.run(cmd, cwd=d, capture_output=True, text=True)
             dt = time.perf_counter() - t0
             if r.returncode == 0 and os.path.exists(os.path.join(d, "OUT.coal")):
                 lines = open(os.path.join(d, "OUT.coal")).read().split("\n")
-                same = all(
-                    lines[2 + b] == "0 %d " % b + " ".join("%g" % x for x in gpu_rates[b]) + " " for b in range(S)
-                )
+                ref_iters = [int(l.rsplit(" ", 1)[1]) for l in r.stderr.split("\n") if l.startswith("Bootstrap ")]
+                diff_per_epoch = np.zeros(E, dtype=np.int64)
+                for b in range(S):
+                    ref_tok = lines[2 + b].split()[2:]
+                    gpu_tok = ["%g" % x for x in gpu_rates[b]]
+                    diff_per_epoch += np.array([a != c for a, c in zip(ref_tok, gpu_tok)], dtype=np.int64)
                 return {
                     "value": S / dt, "unit": "replicates/s", "cores": 1, "kind": "reference",
                     "sample": f"{S} of the benchmark's replicates through the reference binary (.colate_mat hook), "
                               f"{dt:.1f} s wall incl. its start-up",
-                    "coal_text_identical_to_gpu": bool(same),
+                    "coal_text_identical_to_gpu": bool(diff_per_epoch.sum() == 0),
+                    "iterations_identical_to_gpu": bool(ref_iters == [int(x) for x in gpu_iters[:S]]),
+                    "differing_tokens_per_epoch": {str(e): int(n) for e, n in enumerate(diff_per_epoch) if n},
+                    "tokens_compared": int(S * E),
                 }
     # fall back to our C restatement of the reference
     import ctypes
@@ -89,48 +146,103 @@ def cpu_baseline(grid, csh, cns, epochs, gpu_rates, gpu_iters, bins=BINS):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--replicates", type=int, default=B_PER_GPU, help="bootstrap replicates per GPU")
-    ap.add_argument("--bins", default=BINS, help="epoch grid (default: the BASELINE config; 2,7.95,0.05 = 122 epochs)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive (host-pointer ABI) timing")
-    args = ap.parse_args()
+def emit(out):
+    """ONE JSON line on stdout (NaN / inf are not JSON: they go out as null)."""
+    def clean(x):
+        if isinstance(x, dict):
+            return {k: clean(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [clean(v) for v in x]
+        if isinstance(x, float) and not np.isfinite(x):
+            return None
+        return x
 
+    print(json.dumps(clean(out)), flush=True)
+
+
+def write_colate_mat(path, grid, csh, cns):
+    with open(path, "w") as f:
+        f.write(" ".join("%.17g" % x for x in grid) + "\n")
+        for b in range(csh.shape[0]):
+            f.write(" ".join("%.17g" % x for x in csh[b]) + "\n")
+            f.write(" ".join("%.17g" % x for x in cns[b]) + "\n")
+
+
+def cxx_rccl_check(colate_amd, nranks, grid, csh, cns, epochs, bins):
+    """The C++ form of the multi-GPU path on this box's GPUs: `Colate --ranks N` forks N processes (one per GPU),
+    each runs its replicate range, ONE ncclAllGather (colate_comm.cpp) collects them, rank 0 writes the .coal.
+    Checked against this process's own single-GPU run of the same replicates; bounded by a 120 s timeout."""
+    cli = os.path.join(ROOT, "colate_amd", "bin", "Colate")
+    S = min(csh.shape[0], 8 * nranks + 3)  # ragged on purpose when N > 1
+    if not os.path.exists(cli):
+        return {"ranks": nranks, "ok": False, "detail": "colate_amd/bin/Colate not built"}
+    rates, iters, _, _ = colate_amd.em_batch(grid, csh[:S], cns[:S], epochs)
+    want = ["0 %d " % b + " ".join("%g" % x for x in rates[b]) + " " for b in range(S)]
+    with tempfile.TemporaryDirectory() as d:
+        write_colate_mat(os.path.join(d, "OUT.colate_mat"), grid, csh[:S], cns[:S])
+        cmd = ["timeout", "-k", "5", "120", cli, "--mode", "mut", "--mut", "dummy", "--bins", bins, "--num_bootstraps", str(S),
+               "--seed", "1", "--ranks", str(nranks), "-o", "OUT"]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, cwd=d, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0 or not os.path.exists(os.path.join(d, "OUT.coal")):
+            return {"ranks": nranks, "ok": False, "seconds": dt, "detail": f"exit {r.returncode}: {r.stderr[-300:]}"}
+        got = open(os.path.join(d, "OUT.coal")).read().split("\n")[2:2 + S]
+        got_iters = [int(l.rsplit(" ", 1)[1]) for l in r.stderr.split("\n") if l.startswith("Bootstrap ")]
+    return {"ranks": nranks, "replicates": S, "seconds": dt,
+            "ok": bool(got == want and got_iters == [int(x) for x in iters]),
+            "what": "Colate --ranks N (fork per GPU, one ncclAllGather in C++) vs this process's one-GPU run: .coal text and iteration counts"}
+
+
+# --------------------------------------------------------------------------------------------- one rank
+def run_rank(args):
     import torch
 
     import colate_amd
+    from colate_amd import distributed as cd
     from colate_amd import workloads
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # COLATE_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks
+    # (ranks share devices, the gather goes through host memory); never the measured setup
+    backend = os.environ.get("COLATE_BENCH_BACKEND", "nccl")
+    # COLATE_BENCH_DRY=1 (tests/test_bench_launcher.py, no GPU): everything but the kernel -- rank spawning, rendezvous,
+    # sharding, the packed all-gather (gloo), the JSON line; `value` is null and the line says so
+    dry = os.environ.get("COLATE_BENCH_DRY") == "1"
+    if dry:
+        backend = "gloo"
+    ndev = 0 if dry else torch.cuda.device_count()
+    if ndev < 1 and not dry:
+        sys.exit("bench.py: no GPU visible (colate_amd has no CPU path)")
+    if world > 1 and backend == "nccl" and ndev < world:
+        sys.exit(f"bench.py: --gpus {world} needs {world} GPUs, {ndev} visible (COLATE_BENCH_BACKEND=gloo rehearses the control flow)")
+    if not dry:
+        torch.cuda.set_device(local_rank % ndev)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        # COLATE_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs than
-        # ranks (ranks share devices, the gather is staged through host memory); never the measured setup
-        backend = os.environ.get("COLATE_BENCH_BACKEND", "nccl")
-        torch.cuda.set_device(local_rank % torch.cuda.device_count())
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % ndev))
         else:
             dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device("cpu") if dry else torch.device("cuda", torch.cuda.current_device())
 
-    B = args.replicates
+    strong = args.total_replicates > 0
+    B_total = args.total_replicates if strong else world * args.replicates
+    lo, hi = cd.shard_bounds(B_total, world, rank)
+    n_local = hi - lo
     grid = colate_amd.age_grid()
     bins = args.bins
     epochs, _ = colate_amd.epochs_from_bins(bins)
     E, A = epochs.size, grid.size
-    # every rank bootstraps its own B replicates of the same genome (weak scaling)
-    csh, cns = workloads.bootstrap_tables(grid, B, nb=115, scale=11.0, seed=12345 + 1000 * rank)
+    if strong:  # one table of B_total replicates, every rank takes its contiguous range
+        csh, cns = workloads.bootstrap_tables(grid, B_total, nb=115, scale=11.0, seed=12345)
+        csh, cns = csh[lo:hi], cns[lo:hi]
+    else:       # every rank bootstraps its own replicates of the same genome
+        csh, cns = workloads.bootstrap_tables(grid, n_local, nb=115, scale=11.0, seed=12345 + 1000 * rank)
 
     f64 = dict(dtype=torch.float64, device=dev)
     d_grid = torch.tensor(grid, **f64)
@@ -138,93 +250,128 @@ def main():
     d_ns = torch.tensor(cns, **f64)
     d_ep = torch.tensor(epochs, **f64)
     d_init = torch.full((E,), colate_amd.DEFAULT_INIT_RATE, **f64)
-    d_rates = torch.empty((B, E), **f64)
-    d_iters = torch.empty((B,), dtype=torch.int32, device=dev)
-    d_ll = torch.empty((B,), **f64)
-    d_flags = torch.empty((B,), dtype=torch.int32, device=dev)
-    d_all = torch.empty((world * B, E), **f64) if world > 1 else None
+    layout = cd.ShardLayout(B_total, E, world)
+    d_out = layout.new_buffer(device=dev)  # the kernel writes its four outputs straight into the packed buffer
+    v_rates, v_ll, v_iters, v_flags = (v[:n_local] for v in layout.views(d_out))
+    h_all = torch.zeros(world * layout.nbytes, dtype=torch.uint8)
+    if not dry:
+        h_all = h_all.pin_memory()
+    on_gpu = not dry and (world == 1 or dist.get_backend() == "nccl")
+    d_all = torch.empty(world * layout.nbytes, dtype=torch.uint8, device=dev) if (world > 1 and on_gpu) else None
+    h_local = None if on_gpu else (layout.new_buffer() if dry else layout.new_buffer(pin_memory=True))
+    stream = None if dry else torch.cuda.current_stream()
 
-    def gather():  # the one collective: B*E doubles per rank
-        if dist.get_backend() == "nccl":
-            dist.all_gather_into_tensor(d_all, d_rates)
-        else:
-            h = d_rates.cpu()
-            h_all = torch.empty((world * B, E), dtype=torch.float64)
-            dist.all_gather_into_tensor(h_all, h)
-            d_all.copy_(h_all)
+    def launch():
+        if dry:
+            v_iters.fill_(1001)
+        elif n_local:
+            colate_amd.em_batch_device(d_grid, d_sh, d_ns, d_ep, d_init, v_rates, v_iters, v_ll, v_flags, stream=stream)
 
-    def step():
-        colate_amd.em_batch_device(d_grid, d_sh, d_ns, d_ep, d_init, d_rates, d_iters, d_ll, d_flags)
-        if world > 1:
-            gather()
+    def sync():
+        if stream is not None:
+            stream.synchronize()
+
+    def step(events=None):
+        """counts resident in HBM -> every rank holds all B_total results in host memory"""
+        if events:
+            events[0].record(stream)  # on the stream the kernel is launched on
+        launch()
+        if events:
+            events[1].record(stream)
+        if world == 1:
+            h_all.copy_(d_out, non_blocking=True)
+        elif on_gpu:  # the one collective: RCCL all-gather of (8E+16) bytes per replicate, then one D2H copy
+            cd.all_gather_shards(d_out, layout, dist, out=d_all)
+            h_all.copy_(d_all, non_blocking=True)
+        else:         # gloo rehearsal: staged through host memory
+            h_local.copy_(d_out, non_blocking=True)
+            sync()
+            cd.all_gather_shards(h_local, layout, dist, out=h_all)
+        sync()
 
     def fence():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     fence()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = None if dry else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()  # on the stream the kernel is launched on (torch's current stream)
-        colate_amd.em_batch_device(d_grid, d_sh, d_ns, d_ep, d_init, d_rates, d_iters, d_ll, d_flags)
-        ev[k][1].record()
-        if world > 1:
-            gather()
+        step(ev[k] if ev else None)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], **f64) if dist.get_backend() == "nccl" else torch.tensor([elapsed], dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cd.collective_device(dist))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if (n_local and ev) else float("nan")
+    rates_all, iters_all, ll_all, flags_all = layout.unpack(h_all)  # every rank has every replicate's results
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    iters = d_iters.cpu().numpy()
-    flags = d_flags.cpu().numpy()
-    rates = d_rates.cpu().numpy()
+    # launches enqueued back to back without the per-step copy and synchronisation (N = 1 only; not `value`)
+    device_only = None
+    if world == 1 and not dry:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            launch()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        device_only = {"value": B_total * args.steps / dt, "unit": "replicates/s", "ms_per_step": 1e3 * dt / args.steps,
+                       "note": "launches enqueued back to back, no per-step copy of the rates to the host and no "
+                               "per-step synchronisation (round 1's definition of `value`)"}
 
+    out = None
     if rank == 0:
-        esteps = int((iters.astype(np.int64) + 1).sum())  # E-steps executed per launch
-        traffic = None  # HBM bytes per launch from the PMC passes committed under profiles/ (same workload only)
+        iters = iters_all[lo:hi]
+        status = colate_amd.status_flags(flags_all)
+        unresolved = colate_amd.unresolved_epochs(flags_all)
+        esteps = int((iters.astype(np.int64) + 1).sum())  # E-steps executed per launch (this rank)
+        pmc = None  # HBM bytes and SQ counters per launch from the PMC passes committed under profiles/ (same workload only)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj["workload"] == {"replicates": B, "epochs": int(E), "age_bins": int(A)}:
-                traffic = tj["hbm_bytes_per_launch"]
+            for entry in json.load(open(os.path.join(ROOT, "profiles", "pmc.json"))):
+                if entry["workload"] == {"replicates": n_local, "epochs": int(E), "age_bins": int(A)}:
+                    pmc = entry
         except (OSError, KeyError, ValueError):
             pass
-        bytes_per_rep_iter = 2 * A * 8 + A * 8 + 3 * E * 8  # 4992 B at E=23
-        # the instantiation colate_em_launch picks for this shape (the name rocprofv3 reports, profiles/)
+        bytes_per_rep_iter = 2 * A * 8 + A * 8 + 3 * E * 8  # SURVEY.md section 8(d): 4992 B at E=23
+        variant = "dry-run" if dry else colate_amd.em_kernel_variant(n_local, E)
         nch = 1 if E <= 64 else (2 if E <= 128 else 4)
         rows = (1 if E <= 16 else (2 if E <= 32 else 4)) if nch == 1 else 4
-        cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        variant = os.environ.get("COLATE_EM_VARIANT")
-        tput = nch <= 2 and (variant == "throughput" or (variant != "latency" and B > 2 * cus))
-        kernel_name = f"em_kernel<0, {nch}, {rows}, {'true' if tput else 'false'}>"
+        kernel_name = f"em_kernel<0, {nch}, {rows}, {'true' if variant == 'throughput' else 'false'}>"
+        cus = 256 if dry else torch.cuda.get_device_properties(dev).multi_processor_count
         achieved = esteps * bytes_per_rep_iter / (kern_ms * 1e-3) / 1e9
+        crit_iters = int(iters.max()) + 1  # the launch lasts as long as its slowest replicate (B <= #CUs: all run at once)
+        waves = -(-n_local // cus)
         out = {
             "metric": "bootstrap replicates/sec to EM convergence, whole-genome SGDP mut, 20 epochs",
-            "value": world * B * args.steps / elapsed,
+            "value": None if dry else B_total * args.steps / elapsed,
             "unit": "replicates/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "DRY RUN: control flow only, the EM kernel was not launched (COLATE_BENCH_DRY=1)" if dry else "synthetic",
             "config": {
                 "workload": f"whole-genome-like LBK-vs-Loschbour-shaped count tables (nb=115 blocks), "
-                            f"num_bootstrap={B} per GPU, --bins {bins} (E={E} epochs), A={A} age bins, "
-                            f"EM to the reference stop rule (min 1001 iterations)",
-                "replicates_per_gpu": B, "epochs": E, "age_bins": A,
-                "parallelism": f"replicates sharded over {world} GPU(s), one RCCL all-gather of rates per step",
-                "em_iterations_mean": float(iters.mean()), "flags_nonzero": int((flags != 0).sum()),
+                            + (f"num_bootstrap={B_total} sharded over {world} GPU(s)" if strong else f"num_bootstrap={args.replicates} per GPU")
+                            + f", --bins {bins} (E={E} epochs), A={A} age bins, EM to the reference stop rule (min 1001 iterations)",
+                "replicates_total": B_total, "replicates_rank0": n_local, "epochs": E, "age_bins": A,
+                "parallelism": f"replicates sharded over {world} GPU(s), one "
+                               + ("RCCL" if (world > 1 and on_gpu) else ("gloo (rehearsal)" if world > 1 else "(no)"))
+                               + " all-gather of rates/loglik/iterations/flags per step",
+                "step": "EM kernel launch -> all-gather (N > 1) -> results copied to host memory -> stream synchronised, all timed",
+                "em_iterations_mean": float(iters_all.mean()), "status_flags_nonzero": int((status != 0).sum()),
+                "unresolved_epochs_max": int(unresolved.max()),
             },
             "roofline": {
                 "bound": "hbm",
@@ -232,30 +379,57 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
                 "kernel": kernel_name,
+                "kernel_build": variant,
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_launch": esteps * bytes_per_rep_iter,
                 "note": "algorithmic bytes = (2*A*8 + A*8 + 3*E*8) B per replicate-iteration x E-steps per launch "
-                        "(SURVEY.md §8d); the kernel keeps all of it on chip, compulsory HBM traffic is "
-                        "(2*A + E)*8 B per replicate, so the real limiter is FP64 VALU latency (DESIGN.md §5)",
+                        "(SURVEY.md section 8d); the kernel keeps all of it on chip (compulsory HBM traffic is "
+                        "(2*A + E)*8 B per replicate, see `traffic`), so this fraction only says that nothing is re-read; "
+                        "what bounds the kernel is in `latency`",
+                "latency": {
+                    "what": "the kernel is bound by the latency of one EM iteration's chain of dependent FP64 instructions "
+                            "(one workgroup per replicate; iterations are sequential by construction of EM)",
+                    "workgroups": n_local, "cus": cus, "cus_occupied": min(n_local, cus), "workgroup_rounds": waves,
+                    "em_iterations_on_critical_path": crit_iters * waves,
+                    "ns_per_em_iteration": 1e6 * kern_ms / (crit_iters * waves),
+                    "cycles_per_em_iteration_at_peak_clock": kern_ms * 1e-3 * PEAK_CLOCK_HZ / (crit_iters * waves),
+                    "pmc": ({k: pmc[k] for k in pmc if k not in ("workload", "hbm_bytes_per_launch")} if pmc else None),
+                },
             },
         }
-        if world == 1 and not args.no_host_path:
-            # PCIe-inclusive rate through the host-pointer entry point (hipMalloc + copies + launch + copies
-            # back inside the call); reported beside `value`, never as it
-            colate_amd.em_batch(grid, csh, cns, epochs)
-            t1 = time.perf_counter()
-            for _ in range(5):
-                colate_amd.em_batch(grid, csh, cns, epochs)
-            out["host_path"] = {"value": 5 * B / (time.perf_counter() - t1), "unit": "replicates/s",
-                                "note": "colate_em_batch with host buffers, PCIe and allocation inclusive"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(grid, csh, cns, epochs, rates, iters, bins)
-        print(json.dumps(out), flush=True)
+        if device_only:
+            out["device_only"] = device_only
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank != 0:
+        return
+    if dry:
+        emit(out)
+        return
+    if world == 1 and not args.no_host_path:
+        # PCIe-inclusive rate through the host-pointer entry point (staging copies + launch + copy back inside
+        # the call, on the library's cached workspace); reported beside `value`, never as it
+        colate_amd.em_batch(grid, csh, cns, epochs)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            colate_amd.em_batch(grid, csh, cns, epochs)
+        out["host_path"] = {"value": 5 * n_local / (time.perf_counter() - t1), "unit": "replicates/s",
+                            "note": "colate_em_batch with host buffers: PCIe-inclusive"}
+    if not args.no_cxx_rccl_check:
+        out["cxx_rccl"] = cxx_rccl_check(colate_amd, world, grid, csh, cns, epochs, bins)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(grid, csh, cns, epochs, rates_all[lo:hi], iters_all[lo:hi], bins)
+    emit(out)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -13,6 +13,11 @@ from .api import (  # noqa: F401
     FLAG_MAXITER,
     FLAG_NAN,
     FLAG_NEG,
+    FLAG_UNRESOLVED,
+    STATUS_MASK,
+    em_kernel_variant,
+    status_flags,
+    unresolved_epochs,
     Rng,
     age_grid,
     bootstrap_counts,

@@ -30,6 +30,7 @@ SIGNATURES = {
     "colate_last_error": (c_char_p, []),
     "colate_device_count": (c_int, []),
     "colate_set_device": (c_int, [c_int]),
+    "colate_em_kernel_variant": (c_int, [c_int, c_int]),
     "colate_em_batch": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "colate_em_batch_device": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
@@ -54,6 +55,15 @@ SIGNATURES = {
     "colate_bootstrap_counts_device": (c_int, [c_int, c_int, c_int, c_void_p, c_double] + [c_void_p] * 9),
     "colate_bootstrap_em_batch": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_double] + [c_void_p] * 7
                                   + [c_int, c_int, c_double, c_double] + [c_void_p] * 6),
+    "colate_release_workspace": (c_int, []),
+    "colate_shard_bounds": (c_int, [c_int, c_int, c_int, ip, ip]),
+    "colate_comm_unique_id": (c_int, [c_void_p]),
+    "colate_comm_create": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "colate_comm_destroy": (c_int, [c_void_p]),
+    "colate_em_batch_allgather": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "colate_bootstrap_em_batch_allgather": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_double] + [c_void_p] * 7
+                                            + [c_int, c_int, c_double, c_double] + [c_void_p] * 4),
     "colate_write_coal": (c_int, [c_char_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int]),
     "colate_mut_main": (c_int, [c_int, ctypes.POINTER(c_char_p)]),
 }

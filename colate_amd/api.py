@@ -6,7 +6,8 @@ import numpy as np
 
 from ._lib import ColateError, c_char_p, c_int, check, lib  # noqa: F401
 
-FLAG_NAN, FLAG_NEG, FLAG_MAXITER = 1, 2, 4
+FLAG_NAN, FLAG_NEG, FLAG_MAXITER, FLAG_UNRESOLVED = 1, 2, 4, 8
+STATUS_MASK = 0x07  # the error-like bits of out_flags (NaN / negative / iteration cap)
 DEFAULT_MAX_ITER = 100000
 DEFAULT_MIN_ITER = 1000
 DEFAULT_REL_TOL = 1e-7
@@ -29,6 +30,25 @@ def version():
 
 def device_count():
     return lib.colate_device_count()
+
+
+def unresolved_epochs(flags):
+    """COLATE_UNRESOLVED_EPOCHS: how many trailing epochs of each replicate are below the resolution of the
+    reference's arithmetic (include/colate_amd.h, COLATE_FLAG_UNRESOLVED)."""
+    return (np.asarray(flags).astype(np.int64) & 0xFFFFFFFF) >> 8
+
+
+def status_flags(flags):
+    """The error-like bits of out_flags (NaN / negative / iteration cap); 0 = the replicate ran clean."""
+    return np.asarray(flags) & STATUS_MASK
+
+
+EM_VARIANTS = ("latency-ilp", "latency", "throughput")
+
+
+def em_kernel_variant(B, E):
+    """Which build of the EM kernel a batch of this shape runs on the current device."""
+    return EM_VARIANTS[check(lib.colate_em_kernel_variant(int(B), int(E)))]
 
 
 def age_grid():

@@ -14,7 +14,8 @@
 #include "colate_internal.h"
 #include "em_kernels.h"
 
-static_assert(COLATE_FLAG_NAN == 1 && COLATE_FLAG_NEG == 2 && COLATE_FLAG_MAXITER == 4, "flags");
+static_assert(COLATE_FLAG_NAN == 1 && COLATE_FLAG_NEG == 2 && COLATE_FLAG_MAXITER == 4 && COLATE_FLAG_UNRESOLVED == 8 &&
+                  COLATE_UNRESOLVED_SHIFT == 8, "flags");
 
 namespace colate {
 
@@ -96,6 +97,129 @@ struct DevBuf {
   }
 };
 
+// ---- per-thread workspace of the host-pointer entry points -------------------------------------------
+// One device buffer, one pinned host staging buffer and one stream per calling thread, grown on demand and
+// kept between calls (colate_release_workspace frees them): a call costs one staged host-to-device copy,
+// the launch(es), one device-to-host copy and one stream synchronisation instead of nine hipMalloc/hipFree
+// and nine synchronous copies.  Never freed implicitly (a destructor at process exit would run after the HIP
+// runtime has shut down).
+struct Workspace {
+  int device = -1;
+  char* d = nullptr;
+  size_t dcap = 0;
+  char* h = nullptr;
+  size_t hcap = 0;
+  hipStream_t stream = nullptr;
+
+  void release() {
+    if (device >= 0) {
+      int cur = -1;
+      (void)hipGetDevice(&cur);
+      if (cur != device) (void)hipSetDevice(device);
+      if (stream) (void)hipStreamDestroy(stream);
+      if (d) (void)hipFree(d);
+      if (h) (void)hipHostFree(h);
+      if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+    }
+    *this = Workspace();
+  }
+  int reserve(size_t dbytes, size_t hbytes) {
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != device) {  // the thread moved to another GPU: start over there
+      release();
+      device = cur;
+    }
+    if (!stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (dbytes > dcap) {
+      if (d) (void)hipFree(d);
+      d = nullptr, dcap = 0;
+      const size_t want = dbytes + dbytes / 4 + 4096;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), want));
+      dcap = want;
+    }
+    if (hbytes > hcap) {
+      if (h) (void)hipHostFree(h);
+      h = nullptr, hcap = 0;
+      const size_t want = hbytes + hbytes / 4 + 4096;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h), want, hipHostMallocDefault));
+      hcap = want;
+    }
+    return COLATE_OK;
+  }
+};
+static thread_local Workspace g_ws;
+
+// One staged call on the workspace: declare what goes in, what stays on the device and what comes out,
+// commit() (one H2D copy), launch on stream(), finish() (one D2H copy, synchronise, scatter to the caller).
+class Stage {
+ public:
+  template <typename T>
+  int in(const T* host, size_t n) {
+    return add(kIn, host, nullptr, n * sizeof(T));
+  }
+  template <typename T>
+  int out(T* host, size_t n) {  // host may be NULL: the space exists on the device, nothing is returned
+    return add(kOut, nullptr, host, n * sizeof(T));
+  }
+  template <typename T>
+  int scratch(size_t n) {
+    return add(kScratch, nullptr, nullptr, n * sizeof(T));
+  }
+  template <typename T>
+  T* dev(int idx) const {
+    return reinterpret_cast<T*>(ws_->d + seg_[idx].doff);
+  }
+  hipStream_t stream() const { return ws_->stream; }
+
+  int commit() {
+    size_t sizes[3] = {0, 0, 0};
+    for (Seg& s : seg_) {
+      s.koff = sizes[s.kind];
+      sizes[s.kind] += round_up(s.bytes);
+    }
+    const size_t base[3] = {0, sizes[kIn], sizes[kIn] + sizes[kScratch]};  // device: in | scratch | out
+    for (Seg& s : seg_) s.doff = base[s.kind] + s.koff;
+    in_bytes_ = sizes[kIn], out_bytes_ = sizes[kOut], out_base_ = base[kOut];
+    ws_ = &g_ws;
+    if (int rc = ws_->reserve(base[kOut] + sizes[kOut], sizes[kIn] + sizes[kOut])) return rc;  // host: in | out
+    for (const Seg& s : seg_)
+      if (s.kind == kIn && s.bytes) std::memcpy(ws_->h + s.koff, s.src, s.bytes);
+    if (in_bytes_) HIP_TRY(hipMemcpyAsync(ws_->d, ws_->h, in_bytes_, hipMemcpyHostToDevice, ws_->stream));
+    return COLATE_OK;
+  }
+  int finish() {
+    char* hout = ws_->h + in_bytes_;
+    if (out_bytes_) HIP_TRY(hipMemcpyAsync(hout, ws_->d + out_base_, out_bytes_, hipMemcpyDeviceToHost, ws_->stream));
+    HIP_TRY(hipStreamSynchronize(ws_->stream));
+    for (const Seg& s : seg_)
+      if (s.kind == kOut && s.dst && s.bytes) std::memcpy(s.dst, hout + s.koff, s.bytes);
+    return COLATE_OK;
+  }
+  // staged host copy of an `out` segment after finish() (for values the caller inspects before returning them)
+  template <typename T>
+  const T* host_out(int idx) const {
+    return reinterpret_cast<const T*>(ws_->h + in_bytes_ + seg_[idx].koff);
+  }
+
+ private:
+  enum Kind { kIn = 0, kScratch = 1, kOut = 2 };
+  struct Seg {
+    Kind kind;
+    const void* src;
+    void* dst;
+    size_t bytes, koff = 0, doff = 0;
+  };
+  static size_t round_up(size_t b) { return (b + 255) & ~size_t(255); }
+  int add(Kind k, const void* src, void* dst, size_t bytes) {
+    seg_.push_back(Seg{k, src, dst, bytes});
+    return (int)seg_.size() - 1;
+  }
+  std::vector<Seg> seg_;
+  Workspace* ws_ = nullptr;
+  size_t in_bytes_ = 0, out_bytes_ = 0, out_base_ = 0;
+};
+
 static int launch(const ColateEmArgs& a, hipStream_t s) {
   if (a.B == 0) return COLATE_OK;
   hipError_t e = colate_em_launch(a, s);
@@ -122,6 +246,12 @@ int colate_device_count(void) {
 int colate_set_device(int ordinal) {
   HIP_TRY(hipSetDevice(ordinal));
   return COLATE_OK;
+}
+
+int colate_em_kernel_variant(int B, int E) {
+  if (B < 0 || E < 1 || E > COLATE_EM_MAX_E) return fail(COLATE_EINVAL, "bad sizes B=%d E=%d", B, E);
+  if (int rc = ensure_device()) return rc;
+  return colate_em_variant(B, E);
 }
 
 int colate_em_batch_device(int B, int E, int A, const double* age_grid, const double* cnt_shared,
@@ -163,43 +293,44 @@ int colate_em_estep_device(int B, int E, int A, const double* age_grid, const do
   return launch(a, static_cast<hipStream_t>(hip_stream));
 }
 
-int colate_em_batch(int B, int E, int A, const double* age_grid, const double* cnt_shared,
-                    const double* cnt_notshared, const double* epochs, const double* init_rates,
-                    int max_iter, int min_iter, double rel_tol, double rate_floor,
-                    double* out_rates, int* out_iters, double* out_loglik, int* out_flags) {
+// host-pointer EM on the workspace; per_row: epochs / init_rates are [B][E] instead of [E]
+static int em_batch_host(bool per_row, int B, int E, int A, const double* age_grid, const double* cnt_shared,
+                         const double* cnt_notshared, const double* epochs, const double* init_rates,
+                         int max_iter, int min_iter, double rel_tol, double rate_floor, double* out_rates,
+                         int* out_iters, double* out_loglik, int* out_flags) {
   if (int rc = check_sizes(B, E, A)) return rc;
   if (!age_grid || !cnt_shared || !cnt_notshared || !epochs || !init_rates || !out_rates ||
       !out_iters || !out_loglik || !out_flags)
     return fail(COLATE_EINVAL, "NULL pointer argument");
-  if (int rc = check_grids(E, A, age_grid, epochs)) return rc;
+  for (int b = 0; b < (per_row ? B : 1); b++)
+    if (int rc = check_grids(E, A, age_grid, epochs + (size_t)b * E)) return rc;
   if (int rc = ensure_device()) return rc;
   if (B == 0) return COLATE_OK;
-  const size_t nBA = (size_t)B * A, nBE = (size_t)B * E;
-  DevBuf d_grid, d_sh, d_ns, d_ep, d_init, d_rates, d_iters, d_ll, d_flags;
-  HIP_TRY(d_grid.alloc(A * sizeof(double)));
-  HIP_TRY(d_sh.alloc(nBA * sizeof(double)));
-  HIP_TRY(d_ns.alloc(nBA * sizeof(double)));
-  HIP_TRY(d_ep.alloc(E * sizeof(double)));
-  HIP_TRY(d_init.alloc(E * sizeof(double)));
-  HIP_TRY(d_rates.alloc(nBE * sizeof(double)));
-  HIP_TRY(d_iters.alloc(B * sizeof(int)));
-  HIP_TRY(d_ll.alloc(B * sizeof(double)));
-  HIP_TRY(d_flags.alloc(B * sizeof(int)));
-  HIP_TRY(hipMemcpy(d_grid.p, age_grid, A * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_sh.p, cnt_shared, nBA * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_ns.p, cnt_notshared, nBA * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_ep.p, epochs, E * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_init.p, init_rates, E * sizeof(double), hipMemcpyHostToDevice));
-  int rc = colate_em_batch_device(B, E, A, d_grid.as<double>(), d_sh.as<double>(),
-                                  d_ns.as<double>(), d_ep.as<double>(), 0, d_init.as<double>(), 0,
-                                  max_iter, min_iter, rel_tol, rate_floor, d_rates.as<double>(),
-                                  d_iters.as<int>(), d_ll.as<double>(), d_flags.as<int>(), nullptr);
-  if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out_rates, d_rates.p, nBE * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_iters, d_iters.p, B * sizeof(int), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_loglik, d_ll.p, B * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_flags, d_flags.p, B * sizeof(int), hipMemcpyDeviceToHost));
+  const size_t nBA = (size_t)B * A, nBE = (size_t)B * E, nEp = per_row ? nBE : (size_t)E;
+  Stage st;
+  const int i_grid = st.in(age_grid, A), i_sh = st.in(cnt_shared, nBA), i_ns = st.in(cnt_notshared, nBA);
+  const int i_ep = st.in(epochs, nEp), i_init = st.in(init_rates, nEp);
+  const int o_rates = st.out(out_rates, nBE), o_ll = st.out(out_loglik, B), o_iters = st.out(out_iters, B),
+            o_flags = st.out(out_flags, B);
+  if (int rc = st.commit()) return rc;
+  if (int rc = colate_em_batch_device(B, E, A, st.dev<double>(i_grid), st.dev<double>(i_sh), st.dev<double>(i_ns),
+                                      st.dev<double>(i_ep), per_row, st.dev<double>(i_init), per_row, max_iter,
+                                      min_iter, rel_tol, rate_floor, st.dev<double>(o_rates), st.dev<int>(o_iters),
+                                      st.dev<double>(o_ll), st.dev<int>(o_flags), st.stream()))
+    return rc;
+  return st.finish();
+}
+
+int colate_em_batch(int B, int E, int A, const double* age_grid, const double* cnt_shared,
+                    const double* cnt_notshared, const double* epochs, const double* init_rates,
+                    int max_iter, int min_iter, double rel_tol, double rate_floor,
+                    double* out_rates, int* out_iters, double* out_loglik, int* out_flags) {
+  return em_batch_host(false, B, E, A, age_grid, cnt_shared, cnt_notshared, epochs, init_rates, max_iter, min_iter,
+                       rel_tol, rate_floor, out_rates, out_iters, out_loglik, out_flags);
+}
+
+int colate_release_workspace(void) {
+  g_ws.release();
   return COLATE_OK;
 }
 
@@ -244,46 +375,35 @@ int colate_bootstrap_em_batch(int B, int nb, int E, int A, const double* age_gri
   if (int rc = ensure_device()) return rc;
   if (B == 0) return COLATE_OK;
   const size_t nT = (size_t)nb * A, nBA = (size_t)B * A, nBE = (size_t)B * E;
-  DevBuf d_grid, d_w, d_t[4], d_sh, d_ns, d_ep, d_init, d_rates, d_iters, d_ll, d_flags, d_status;
-  HIP_TRY(d_grid.alloc(A * sizeof(double)));
-  HIP_TRY(d_w.alloc((size_t)B * nb * sizeof(double)));
-  const double* tabs[4] = {sh_block, ns_block, sh_emp_block, ns_emp_block};
-  for (int k = 0; k < 4; k++) {
-    HIP_TRY(d_t[k].alloc(nT * sizeof(double)));
-    HIP_TRY(hipMemcpy(d_t[k].p, tabs[k], nT * sizeof(double), hipMemcpyHostToDevice));
-  }
-  HIP_TRY(d_sh.alloc(nBA * sizeof(double)));
-  HIP_TRY(d_ns.alloc(nBA * sizeof(double)));
-  HIP_TRY(d_ep.alloc(E * sizeof(double)));
-  HIP_TRY(d_init.alloc(E * sizeof(double)));
-  HIP_TRY(d_rates.alloc(nBE * sizeof(double)));
-  HIP_TRY(d_iters.alloc(B * sizeof(int)));
-  HIP_TRY(d_ll.alloc(B * sizeof(double)));
-  HIP_TRY(d_flags.alloc(B * sizeof(int)));
-  HIP_TRY(d_status.alloc(sizeof(int)));
-  HIP_TRY(hipMemset(d_status.p, 0, sizeof(int)));
-  HIP_TRY(hipMemcpy(d_grid.p, age_grid, A * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_w.p, weights, (size_t)B * nb * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_ep.p, epochs, E * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_init.p, init_rates, E * sizeof(double), hipMemcpyHostToDevice));
-  int rc = colate_bootstrap_counts_device(B, nb, A, d_grid.as<double>(), age, d_w.as<double>(), d_t[0].as<double>(),
-                                          d_t[1].as<double>(), d_t[2].as<double>(), d_t[3].as<double>(),
-                                          d_sh.as<double>(), d_ns.as<double>(), d_status.as<int>(), nullptr);
-  if (rc) return rc;
-  rc = colate_em_batch_device(B, E, A, d_grid.as<double>(), d_sh.as<double>(), d_ns.as<double>(), d_ep.as<double>(), 0,
-                              d_init.as<double>(), 0, max_iter, min_iter, rel_tol, rate_floor, d_rates.as<double>(),
-                              d_iters.as<int>(), d_ll.as<double>(), d_flags.as<int>(), nullptr);
-  if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  int status = 0;
-  HIP_TRY(hipMemcpy(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost));
-  if (status) return fail(COLATE_EINVAL, "sample age outside the age grid");
-  HIP_TRY(hipMemcpy(out_rates, d_rates.p, nBE * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_iters, d_iters.p, B * sizeof(int), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_loglik, d_ll.p, B * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_flags, d_flags.p, B * sizeof(int), hipMemcpyDeviceToHost));
-  if (out_cnt_shared) HIP_TRY(hipMemcpy(out_cnt_shared, d_sh.p, nBA * sizeof(double), hipMemcpyDeviceToHost));
-  if (out_cnt_notshared) HIP_TRY(hipMemcpy(out_cnt_notshared, d_ns.p, nBA * sizeof(double), hipMemcpyDeviceToHost));
+  Stage st;
+  const int i_grid = st.in(age_grid, A), i_w = st.in(weights, (size_t)B * nb);
+  const int i_t0 = st.in(sh_block, nT), i_t1 = st.in(ns_block, nT), i_t2 = st.in(sh_emp_block, nT),
+            i_t3 = st.in(ns_emp_block, nT);
+  const int i_ep = st.in(epochs, E), i_init = st.in(init_rates, E);
+  const int zero = 0;
+  const int i_status = st.in(&zero, 1);  // device int the bootstrap kernel ORs into; read back with the outputs
+  const int o_rates = st.out(out_rates, nBE), o_ll = st.out(out_loglik, B), o_iters = st.out(out_iters, B),
+            o_flags = st.out(out_flags, B);
+  // the count tables stay on the device between the two kernels; they travel back only if asked for
+  const bool want_counts = out_cnt_shared || out_cnt_notshared;
+  const int c_sh = want_counts ? st.out(out_cnt_shared, nBA) : st.scratch<double>(nBA);
+  const int c_ns = want_counts ? st.out(out_cnt_notshared, nBA) : st.scratch<double>(nBA);
+  int status_host = 0;
+  const int o_status = st.out(&status_host, 1);
+  if (int rc = st.commit()) return rc;
+  if (int rc = colate_bootstrap_counts_device(B, nb, A, st.dev<double>(i_grid), age, st.dev<double>(i_w),
+                                              st.dev<double>(i_t0), st.dev<double>(i_t1), st.dev<double>(i_t2),
+                                              st.dev<double>(i_t3), st.dev<double>(c_sh), st.dev<double>(c_ns),
+                                              st.dev<int>(i_status), st.stream()))
+    return rc;
+  if (int rc = colate_em_batch_device(B, E, A, st.dev<double>(i_grid), st.dev<double>(c_sh), st.dev<double>(c_ns),
+                                      st.dev<double>(i_ep), 0, st.dev<double>(i_init), 0, max_iter, min_iter, rel_tol,
+                                      rate_floor, st.dev<double>(o_rates), st.dev<int>(o_iters), st.dev<double>(o_ll),
+                                      st.dev<int>(o_flags), st.stream()))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(st.dev<int>(o_status), st.dev<int>(i_status), sizeof(int), hipMemcpyDeviceToDevice, st.stream()));
+  if (int rc = st.finish()) return rc;
+  if (status_host) return fail(COLATE_EINVAL, "sample age outside the age grid");
   return COLATE_OK;
 }
 
@@ -291,44 +411,10 @@ int colate_em_batch_rows(int B, int E, int A, const double* age_grid, const doub
                          const double* cnt_notshared, const double* epochs, const double* init_rates,
                          int max_iter, int min_iter, double rel_tol, double rate_floor,
                          double* out_rates, int* out_iters, double* out_loglik, int* out_flags) {
-  if (int rc = check_sizes(B, E, A)) return rc;
-  if (!age_grid || !cnt_shared || !cnt_notshared || !epochs || !init_rates || !out_rates ||
-      !out_iters || !out_loglik || !out_flags)
-    return fail(COLATE_EINVAL, "NULL pointer argument");
-  for (int b = 0; b < B; b++)
-    if (int rc = check_grids(E, A, age_grid, epochs + (size_t)b * E)) return rc;
-  if (int rc = ensure_device()) return rc;
-  if (B == 0) return COLATE_OK;
-  const size_t nBA = (size_t)B * A, nBE = (size_t)B * E;
-  DevBuf d_grid, d_sh, d_ns, d_ep, d_init, d_rates, d_iters, d_ll, d_flags;
-  HIP_TRY(d_grid.alloc(A * sizeof(double)));
-  HIP_TRY(d_sh.alloc(nBA * sizeof(double)));
-  HIP_TRY(d_ns.alloc(nBA * sizeof(double)));
-  HIP_TRY(d_ep.alloc(nBE * sizeof(double)));
-  HIP_TRY(d_init.alloc(nBE * sizeof(double)));
-  HIP_TRY(d_rates.alloc(nBE * sizeof(double)));
-  HIP_TRY(d_iters.alloc(B * sizeof(int)));
-  HIP_TRY(d_ll.alloc(B * sizeof(double)));
-  HIP_TRY(d_flags.alloc(B * sizeof(int)));
-  HIP_TRY(hipMemcpy(d_grid.p, age_grid, A * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_sh.p, cnt_shared, nBA * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_ns.p, cnt_notshared, nBA * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_ep.p, epochs, nBE * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_init.p, init_rates, nBE * sizeof(double), hipMemcpyHostToDevice));
-  int rc = colate_em_batch_device(B, E, A, d_grid.as<double>(), d_sh.as<double>(),
-                                  d_ns.as<double>(), d_ep.as<double>(), 1, d_init.as<double>(), 1,
-                                  max_iter, min_iter, rel_tol, rate_floor, d_rates.as<double>(),
-                                  d_iters.as<int>(), d_ll.as<double>(), d_flags.as<int>(), nullptr);
-  if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out_rates, d_rates.p, nBE * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_iters, d_iters.p, B * sizeof(int), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_loglik, d_ll.p, B * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_flags, d_flags.p, B * sizeof(int), hipMemcpyDeviceToHost));
-  return COLATE_OK;
+  return em_batch_host(true, B, E, A, age_grid, cnt_shared, cnt_notshared, epochs, init_rates, max_iter, min_iter,
+                       rel_tol, rate_floor, out_rates, out_iters, out_loglik, out_flags);
 }
 
-// per_row: epochs and init_rates are [B][E] (one grid per replicate row) instead of [E]
 static int em_batch_sharded_impl(bool per_row, int num_devices, const int* devices, int B, int E, int A,
                                  const double* age_grid, const double* cnt_shared,
                                  const double* cnt_notshared, const double* epochs,
@@ -352,13 +438,20 @@ static int em_batch_sharded_impl(bool per_row, int num_devices, const int* devic
   HIP_TRY(hipGetDevice(&prev_dev));
   struct Shard {
     int lo = 0, n = 0;
+    bool launched = false;
     hipStream_t stream = nullptr;
     DevBuf grid, sh, ns, ep, init, rates, iters, ll, flags;
   };
   std::vector<Shard> shards(num_devices);
   int rc = COLATE_OK;
   const int base = B / num_devices, rem = B % num_devices;
-  // enqueue everything (copies in, kernel, copies out) on one stream per shard, then wait for all
+  auto step = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == COLATE_OK) rc = hip_fail(e, what);
+    return e == hipSuccess;
+  };
+  // Pass 1: per shard, allocate, copy in and launch.  The caller's buffers are pageable, so each copy-in blocks
+  // the host until it is done -- but nothing here waits for a KERNEL, so every GPU has its launch queued before
+  // the first result is asked for.
   for (int d = 0; d < num_devices && rc == COLATE_OK; d++) {
     Shard& s = shards[d];
     s.lo = d * base + (d < rem ? d : rem);
@@ -366,12 +459,8 @@ static int em_batch_sharded_impl(bool per_row, int num_devices, const int* devic
     if (s.n == 0) continue;
     const size_t nA = (size_t)s.n * A, nE = (size_t)s.n * E;
     const size_t nEp = per_row ? nE : (size_t)E, ep_off = per_row ? (size_t)s.lo * E : 0;  // this shard's epoch rows
-    auto step = [&](hipError_t e, const char* what) {
-      if (e != hipSuccess && rc == COLATE_OK) rc = hip_fail(e, what);
-      return e == hipSuccess;
-    };
     if (!step(hipSetDevice(devices[d]), "hipSetDevice")) break;
-    if (!step(hipStreamCreate(&s.stream), "hipStreamCreate")) break;
+    if (!step(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate")) break;
     bool ok = step(s.grid.alloc(A * sizeof(double)), "hipMalloc") && step(s.sh.alloc(nA * sizeof(double)), "hipMalloc") &&
               step(s.ns.alloc(nA * sizeof(double)), "hipMalloc") && step(s.ep.alloc(nEp * sizeof(double)), "hipMalloc") &&
               step(s.init.alloc(nEp * sizeof(double)), "hipMalloc") && step(s.rates.alloc(nE * sizeof(double)), "hipMalloc") &&
@@ -392,10 +481,18 @@ static int em_batch_sharded_impl(bool per_row, int num_devices, const int* devic
       rc = r2;
       break;
     }
-    ok = step(hipMemcpyAsync(out_rates + (size_t)s.lo * E, s.rates.p, nE * sizeof(double), hipMemcpyDeviceToHost, s.stream), "copy") &&
-         step(hipMemcpyAsync(out_iters + s.lo, s.iters.p, s.n * sizeof(int), hipMemcpyDeviceToHost, s.stream), "copy") &&
-         step(hipMemcpyAsync(out_loglik + s.lo, s.ll.p, s.n * sizeof(double), hipMemcpyDeviceToHost, s.stream), "copy") &&
-         step(hipMemcpyAsync(out_flags + s.lo, s.flags.p, s.n * sizeof(int), hipMemcpyDeviceToHost, s.stream), "copy");
+    s.launched = true;
+  }
+  // Pass 2: collect.  The first copy-out of a shard waits for that shard's kernel only; the other GPUs keep running.
+  for (int d = 0; d < num_devices && rc == COLATE_OK; d++) {
+    Shard& s = shards[d];
+    if (!s.launched) continue;
+    const size_t nE = (size_t)s.n * E;
+    if (!step(hipSetDevice(devices[d]), "hipSetDevice")) break;
+    bool ok = step(hipMemcpyAsync(out_rates + (size_t)s.lo * E, s.rates.p, nE * sizeof(double), hipMemcpyDeviceToHost, s.stream), "copy") &&
+              step(hipMemcpyAsync(out_iters + s.lo, s.iters.p, s.n * sizeof(int), hipMemcpyDeviceToHost, s.stream), "copy") &&
+              step(hipMemcpyAsync(out_loglik + s.lo, s.ll.p, s.n * sizeof(double), hipMemcpyDeviceToHost, s.stream), "copy") &&
+              step(hipMemcpyAsync(out_flags + s.lo, s.flags.p, s.n * sizeof(int), hipMemcpyDeviceToHost, s.stream), "copy");
     if (!ok) break;
   }
   for (int d = 0; d < num_devices; d++) {  // always drain and release, also after an error
@@ -405,7 +502,7 @@ static int em_batch_sharded_impl(bool per_row, int num_devices, const int* devic
     hipError_t e = hipStreamSynchronize(s.stream);
     if (e != hipSuccess && rc == COLATE_OK) rc = hip_fail(e, "hipStreamSynchronize");
     (void)hipStreamDestroy(s.stream);
-    s.grid = DevBuf();
+    s.stream = nullptr;
   }
   for (int d = 0; d < num_devices; d++) {  // free on the owning device
     (void)hipSetDevice(devices[d]);
@@ -448,32 +545,16 @@ int colate_em_estep(int B, int E, int A, const double* age_grid, const double* c
   if (int rc = ensure_device()) return rc;
   if (B == 0) return COLATE_OK;
   const size_t nBA = (size_t)B * A, nBE = (size_t)B * E;
-  DevBuf d_grid, d_sh, d_ns, d_ep, d_rates, d_num, d_den, d_ll, d_flags;
-  HIP_TRY(d_grid.alloc(A * sizeof(double)));
-  HIP_TRY(d_sh.alloc(nBA * sizeof(double)));
-  HIP_TRY(d_ns.alloc(nBA * sizeof(double)));
-  HIP_TRY(d_ep.alloc(E * sizeof(double)));
-  HIP_TRY(d_rates.alloc(nBE * sizeof(double)));
-  HIP_TRY(d_num.alloc(nBE * sizeof(double)));
-  HIP_TRY(d_den.alloc(nBE * sizeof(double)));
-  HIP_TRY(d_ll.alloc(B * sizeof(double)));
-  HIP_TRY(d_flags.alloc(B * sizeof(int)));
-  HIP_TRY(hipMemcpy(d_grid.p, age_grid, A * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_sh.p, cnt_shared, nBA * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_ns.p, cnt_notshared, nBA * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_ep.p, epochs, E * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_rates.p, rates, nBE * sizeof(double), hipMemcpyHostToDevice));
-  int rc = colate_em_estep_device(B, E, A, d_grid.as<double>(), d_sh.as<double>(),
-                                  d_ns.as<double>(), d_ep.as<double>(), d_rates.as<double>(),
-                                  d_num.as<double>(), d_den.as<double>(), d_ll.as<double>(),
-                                  d_flags.as<int>(), nullptr);
-  if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(num_acc, d_num.p, nBE * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(den_acc, d_den.p, nBE * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(loglik, d_ll.p, B * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(flags, d_flags.p, B * sizeof(int), hipMemcpyDeviceToHost));
-  return COLATE_OK;
+  Stage st;
+  const int i_grid = st.in(age_grid, A), i_sh = st.in(cnt_shared, nBA), i_ns = st.in(cnt_notshared, nBA);
+  const int i_ep = st.in(epochs, E), i_rates = st.in(rates, nBE);
+  const int o_num = st.out(num_acc, nBE), o_den = st.out(den_acc, nBE), o_ll = st.out(loglik, B), o_flags = st.out(flags, B);
+  if (int rc = st.commit()) return rc;
+  if (int rc = colate_em_estep_device(B, E, A, st.dev<double>(i_grid), st.dev<double>(i_sh), st.dev<double>(i_ns),
+                                      st.dev<double>(i_ep), st.dev<double>(i_rates), st.dev<double>(o_num),
+                                      st.dev<double>(o_den), st.dev<double>(o_ll), st.dev<int>(o_flags), st.stream()))
+    return rc;
+  return st.finish();
 }
 
 }  // extern "C"

@@ -12,6 +12,8 @@
 #define COLATE_FLAG_NAN 1      // coal.cpp:3711-3712, coal_EM.cpp:128-129, 351
 #define COLATE_FLAG_NEG 2      // coal.cpp:3713-3714
 #define COLATE_FLAG_MAXITER 4  // iteration cap reached without meeting the stop rule
+#define COLATE_FLAG_UNRESOLVED 8  // some trailing epochs are below the resolution of the reference's arithmetic
+#define COLATE_UNRESOLVED_SHIFT 8 // out_flags >> 8 = number of such trailing epochs
 
 struct ColateEmArgs {
   int B, E, A;
@@ -35,6 +37,9 @@ struct ColateEmArgs {
 
 size_t colate_em_lds_bytes(int E, int A);
 hipError_t colate_em_launch(const ColateEmArgs& args, hipStream_t stream);
+// which build of the kernel a launch of this shape picks on the current device:
+// 0 = latency (max-ilp build), 1 = latency (default build), 2 = throughput (em_kernels.hip)
+int colate_em_variant(int B, int E);
 
 // block bootstrap on the device (bootstrap_kernel.hip)
 hipError_t colate_bootstrap_launch(int B, int nb, int A, const double* age_grid, double age,

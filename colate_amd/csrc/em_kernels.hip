@@ -1,956 +1,18 @@
-// colate_amd/csrc/em_kernels.hip -- the EM hot path of `Colate --mode mut` on gfx950.
+// colate_amd/csrc/em_kernels.hip -- instantiation and dispatch of the EM kernel (template in em_kernel_impl.hpp).
 //
-// Replaces, for B bootstrap replicates at once, the reference's
-//   bootstrap EM driver            include/coal/coal.cpp:3675-3827
-//   coal_EM ctor / get_AB          include/coal/coal_EM.hpp:38-50, coal_EM.cpp:97-151
-//   coal_EM::EM_shared/_notshared  include/coal/coal_EM.cpp:153-295, 297-468 (age_begin == age_end)
-//   E-step accumulation            include/coal/coal.cpp:3704-3733
-//   M-step, floor, stop rule       include/coal/coal.cpp:3771-3815, 3822-3825
-//
-// One workgroup owns one replicate and runs all of its EM iterations inside one
-// launch: counts, age grid, epochs and the current rates never leave the CU
-// (registers + LDS), so HBM sees each replicate's 2*A counts once on the way in
-// and E rates on the way out.  Each iteration is a short chain of dependent
-// double-precision instructions, and BASELINE configs put <= 256 replicates on a
-// 256-CU GPU (one workgroup per CU), so the kernel is built for LATENCY: what
-// costs is the number of instructions ONE wave has to issue per iteration
-// (a lone wave issues a dependent v_fma_f64 every ~7 cycles, tools/ubench.hip).
-// The work of an iteration is therefore split by ROLE over waves that run
-// concurrently on different SIMDs:
-//
-//   role A ("shared"):     cs scan, S_e = exp(-cs_e), shared-bin terms, suffix scan RS, N/D shared parts
-//   role B ("not shared"): cs scan, q_e, p_e, beta_e, 1/lambda, not-shared-bin terms, affine scan T,
-//                          N/D not-shared parts
-//
-// with age bins one per lane (compacted to the bins that carry data: NB groups of
-// 64, so 2*NB waves; waves without bins retire before the loop, which keeps the
-// s_barrier cheap), epoch e in lane e & 63 (chunk e >> 6) of the role leaders,
-// and three workgroup barriers per iteration (epoch values -> bins -> per-epoch
-// sums -> rates).  Per-epoch sums of the per-bin terms are reduced in registers
-// (row-segmented DPP) and handed over through an LDS tile at static "tail" slots.
-// For batches far beyond the CU count the same code is instantiated as a THROUGHPUT
-// variant (template flag TPUT: two waves per replicate that loop over the bin groups;
-// see em_kernel below), with bit-identical results.
-//
-// The reference evaluates exp(log-term - Z) for every (age bin, epoch) pair:
-// O(A*E) transcendentals per iteration.  Here every such term is factored into
-// a per-epoch piece times a per-bin piece, so that the sufficient
-// statistics N_e = sum_b c_b num_e(b), D_e = sum_b c_b denom_e(b) and
-// ll = sum_b c_b Z_b need O(A + E) transcendentals; sums that telescope in the
-// model are not summed (sum_{j<e} exp(A_j) = 1 - exp(-cs_e); the not-shared
-// normaliser is exp(-cs(age)) whenever the last epoch absorbs).  The formulas
-// the reference evaluates with catastrophic cancellation are kept operand for
-// operand (no fused multiply-add: this file is built with -ffp-contract=off and
-// uses fma only inside em_math.hpp and in recurrences that have no counterpart
-// in the reference).
-#include <hip/hip_runtime.h>
-
+//   shape                                   instantiation                     build
+//   one E-step (colate_em_estep)            <1, NCH, 4, false>                this unit
+//   B <= #CUs, E <= 128                     <0, NCH, EROWS, false> latency    em_kernels_ilp.hip (max-ilp scheduling)
+//   #CUs < B <= 2 x #CUs, E <= 128          <0, NCH, EROWS, false> latency    this unit (3 waves/SIMD: two workgroups per CU)
+//   B > 2 x #CUs, or E > 128                <0, NCH, EROWS, true> throughput  this unit
 #include <cstdlib>
 #include <cstring>
 
-#include "em_kernels.h"
-#include "em_math.hpp"
+#include "em_kernel_impl.hpp"
 
-namespace {
+hipError_t colate_em_launch_latency_ilp(const ColateEmArgs& args, hipStream_t stream);  // em_kernels_ilp.hip
 
-constexpr int kWave = 64;
-enum { O_W = 0, O_N, O_D, kNumBinArrays };  // per-bin values -> epochs: weight (c r | c u), own-epoch num, denom
-enum { G_LAM = 0, G_INV, G_XA, G_P, G_BETA, G_CS, G_S, G_PW, kNumGather };  // per-epoch values in LDS
-
-// ----------------------------------------------------------------- lane plumbing
-__device__ __forceinline__ double readlane_d(double v, int lane) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
-// DPP move of a double.  Lanes whose source is out of range, or whose row is
-// not in ROW_MASK, keep `old` (BOUND == false) or read 0 (BOUND == true).
-template <int CTRL, int ROW_MASK = 0xf, bool BOUND = false>
-__device__ __forceinline__ double dpp_d(double old, double v) {
-  int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, BOUND);
-  int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, BOUND);
-  return __hiloint2double(hi, lo);
-}
-constexpr int ROW_SHR1 = 0x111, ROW_SHR2 = 0x112, ROW_SHR4 = 0x114, ROW_SHR8 = 0x118;
-constexpr int ROW_SHL1 = 0x101, ROW_SHL2 = 0x102, ROW_SHL4 = 0x104, ROW_SHL8 = 0x108;
-constexpr int ROW_BCAST15 = 0x142, ROW_BCAST31 = 0x143, WAVE_SHR1 = 0x138, WAVE_SHL1 = 0x130;
-
-// The epoch-level scans only need to span the lanes that hold epochs: `rows` = number of 16-lane
-// rows in use (uniform), so E <= 16 / <= 32 skip the cross-row steps.
-
-// inclusive prefix sum over the lanes of the first `rows` rows
-__device__ __forceinline__ double wave_prefix_sum(double v, int rows = 4) {
-  v += dpp_d<ROW_SHR1, 0xf, true>(0.0, v);
-  v += dpp_d<ROW_SHR2, 0xf, true>(0.0, v);
-  v += dpp_d<ROW_SHR4, 0xf, true>(0.0, v);
-  v += dpp_d<ROW_SHR8, 0xf, true>(0.0, v);
-  if (rows > 1) v += dpp_d<ROW_BCAST15, 0xa>(0.0, v);
-  if (rows > 2) v += dpp_d<ROW_BCAST31, 0xc>(0.0, v);
-  return v;
-}
-// inclusive suffix sum (lane l: sum of lanes l..), lanes beyond the rows in use must hold 0
-__device__ __forceinline__ double wave_suffix_sum(double v, int lane, int rows = 4) {
-  v += dpp_d<ROW_SHL1, 0xf, true>(0.0, v);
-  v += dpp_d<ROW_SHL2, 0xf, true>(0.0, v);
-  v += dpp_d<ROW_SHL4, 0xf, true>(0.0, v);
-  v += dpp_d<ROW_SHL8, 0xf, true>(0.0, v);
-  if (rows > 1) {
-    const double r1 = readlane_d(v, 16);
-    double add = 0.0;
-    if (rows > 2) {
-      const double r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
-      const double s23 = r2 + r3, s123 = r1 + s23;
-      const int row = lane >> 4;
-      add = row == 0 ? s123 : (row == 1 ? s23 : (row == 2 ? r3 : 0.0));
-    } else {
-      add = (lane >> 4) == 0 ? r1 : 0.0;
-    }
-    v = v + add;
-  }
-  return v;
-}
-// inclusive prefix composition of the affine maps x -> a*x + b (lane order = application order):
-// afterwards (a, b) of lane l is f_l o ... o f_0
-__device__ __forceinline__ void wave_affine_scan(double& a, double& b, int rows = 4) {
-#define COLATE_AFF_STEP(CTRL, RM, BND)             \
-  {                                                \
-    const double as = dpp_d<CTRL, RM>(1.0, a);     \
-    const double bs = dpp_d<CTRL, RM, BND>(0.0, b); \
-    b = em::fma_(a, bs, b);                        \
-    a = a * as;                                    \
-  }
-  COLATE_AFF_STEP(ROW_SHR1, 0xf, true)
-  COLATE_AFF_STEP(ROW_SHR2, 0xf, true)
-  COLATE_AFF_STEP(ROW_SHR4, 0xf, true)
-  COLATE_AFF_STEP(ROW_SHR8, 0xf, true)
-  if (rows > 1) COLATE_AFF_STEP(ROW_BCAST15, 0xa, false)
-  if (rows > 2) COLATE_AFF_STEP(ROW_BCAST31, 0xc, false)
-#undef COLATE_AFF_STEP
-}
-
-#ifdef COLATE_EM_STAMPS
-// diagnostic build only (tools/em_phase_probe.hip): cycle stamps around the phases of an iteration
-__device__ __forceinline__ unsigned long long stamp() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-#define COLATE_STAMP(i)                     \
-  {                                         \
-    const unsigned long long now_ = stamp(); \
-    st_acc[i] += now_ - st_prev;            \
-    st_prev = now_;                         \
-  }
-#else
-#define COLATE_STAMP(i)
-#endif
-
-// Timing-only ablations for tools/em_phase_probe.hip (-DCOLATE_ABL=<bit mask>): each bit removes one
-// piece of the iteration so that its true cost shows up in the kernel time (results are garbage).
-#ifdef COLATE_ABL
-#define COLATE_ABL_HAS(b) (((COLATE_ABL) >> (b)) & 1)
-#else
-#define COLATE_ABL_HAS(b) 0
-#endif
-
-// Marks a rarely-taken branch body: a volatile asm cannot be executed speculatively, so the compiler
-// keeps the branch instead of if-converting it (it otherwise evaluates whole exp()/log() calls of
-// cold paths unconditionally and selects the result).
-#define COLATE_COLD() asm volatile("; cold path")
-
-__device__ __forceinline__ bool finite_pos(double x) { return x > 0.0 && x < __builtin_inf(); }
-
-// wave-local LDS hand-off: earlier ds_writes of this wave are visible to its later ds_reads
-// (the LDS queue is in order per wave); this only stops the compiler from moving them.
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// what the bin phase (P2) needs to know about one age bin
-struct BinStat {
-  double a_b, cnt, tk, tkn, dtk, da, db;  // age, count (this role's kind), epoch start / end / length, age - start, end - age
-  double f1, f2, f4, f8;                  // 1.0 if the lane 1/2/4/8 to the left (same 16-lane row) is in the same epoch
-  int kb, pos;                            // epoch of the bin; position in the compacted tile
-  bool live, last_bin, is_tail;           // carries data; lies in the last epoch; last lane of its (row, epoch) run
-};
-// packed form of the static part, one int per compacted position (throughput variant)
-enum { BF_F1 = 1, BF_F2 = 2, BF_F4 = 4, BF_F8 = 8, BF_TAIL = 16, BF_INRANGE = 32, BF_KB_SHIFT = 8 };
-
-// MODE 0: EM to convergence, 1: one E-step (num/den/ll out).  NCH = epoch chunks of 64 per lane;
-// EROWS = 16-lane rows of a chunk that hold epochs (1, 2 or 4; 4 whenever NCH > 1).
-// TPUT = false: the latency variant described at the top (a wave per role and bin group, one workgroup per CU
-// in mind).  TPUT = true: the THROUGHPUT variant for batches far beyond the number of CUs: the same phases and
-// the same arithmetic (results are bit-identical), but one replicate is two waves (one per role) that walk
-// through the bin groups one after the other, their per-bin statics re-read from LDS: a third of the wave
-// slots and fewer registers per replicate, so three times as many replicates are resident per CU and fill
-// the issue slots that a lone workgroup leaves empty at its barriers.
-template <int MODE, int NCH, int EROWS, bool TPUT>
-__global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
-  extern __shared__ double lds[];
-  const int E = p.E, A = p.A;
-  constexpr int EPAD = NCH * kWave;
-  const int NBMAX = (A + kWave - 1) / kWave;  // bin groups of 64 per role
-  const int AP = NBMAX * kWave;       // >= A
-  const int APZ = AP + 16;            // stride of the per-bin tiles; entries [AP, APZ) stay zero
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int role = wave & 1;          // 0: shared (A), 1: not shared (B)
-  const int grp = wave >> 1;          // waves 2g, 2g+1 own bin group g: the live waves are 0..2*NB-1, one per SIMD
-  const int rep = blockIdx.x;
-
-  // ---- LDS carve-up ----
-  double* s_t = lds;                                 // [EPAD + 1] epoch starts
-  double* s_ep = s_t + EPAD + 1;                     // [kNumGather][EPAD] epoch values (A writes CS,S,PW; B the rest)
-  double* s_out = s_ep + kNumGather * EPAD;          // [2 roles][kNumBinArrays][APZ] per-bin tails
-  double* s_nd = s_out + 2 * kNumBinArrays * APZ;    // [2 roles][2][EPAD] partial N, D per role
-  double* s_cfail = s_nd + 4 * EPAD;                 // [2 roles][APZ] counts of bins whose normaliser failed
-  double* s_cnt = s_cfail + 2 * APZ;                 // [2 roles][APZ] counts
-  double* s_ll = s_cnt + 2 * APZ;                    // [8] per-wave log-likelihood partials
-  double* s_age = s_ll + 8;                          // [AP] age grid (throughput variant)
-  int* s_kb = reinterpret_cast<int*>(s_age + AP);    // [AP + 1] epoch of each bin
-  int* s_fail = s_kb + AP + 1;                       // [8] per-wave "a bin failed" flags
-  int* s_misc = s_fail + 8;                          // [4] nzlo, nzhi, flags
-  int* s_bflags = s_misc + 4;                        // [AP] packed per-position statics (throughput variant)
-
-#ifdef COLATE_EM_TRACE  // diagnostic build (tools/residency_probe.hip): where and when this workgroup ran
-  unsigned long long trace_t0;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trace_t0)::"memory");
-#endif
-  // ------------------------------------------------------------------ prologue
-  const double* epochs = p.epochs + (size_t)rep * p.epochs_stride;
-  for (int i = tid; i < EPAD + 1; i += blockDim.x) s_t[i] = (i < E) ? epochs[i] : 0.0;
-  for (int i = tid; i < kNumGather * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ; i += blockDim.x) s_ep[i] = 0.0;
-  if (tid == 0) {
-    s_misc[0] = A;
-    s_misc[1] = 0;
-    s_misc[2] = 0;
-  }
-  if (tid < 8) {
-    s_ll[tid] = 0.0;
-    s_fail[tid] = 0;
-  }
-  __syncthreads();
-  for (int t = tid; t < AP; t += blockDim.x) {
-    int kb = E;  // padding: beyond every epoch
-    if (t < A) {
-      const double a = p.age_grid[t];
-      const double c1 = p.cnt_sh[(size_t)rep * A + t];
-      const double c2 = p.cnt_ns[(size_t)rep * A + t];
-      const double csh = (c1 > 0) ? c1 : 0.0;  // coal.cpp:3706, 3719: only counts > 0 are visited
-      const double cns = (c2 > 0) ? c2 : 0.0;
-      kb = E - 1;  // coal_EM.cpp:60-95: largest e with epochs[e] <= age (strict `age < epochs[e]`)
-      for (int e = 0; e < E; e++) {
-        if (a < s_t[e]) {
-          kb = e - 1;
-          break;
-        }
-      }
-      if (kb < 0) kb = 0;  // host validates age >= epochs[0]; never taken
-      s_cnt[t] = csh;
-      s_cnt[APZ + t] = cns;
-      if (TPUT) s_age[t] = a;
-      if (csh > 0 || cns > 0) {
-        atomicMin(&s_misc[0], t);
-        atomicMax(&s_misc[1], t + 1);
-      }
-    }
-    s_kb[t] = kb;
-  }
-  if (tid == 0) s_kb[AP] = E + 1;
-  __syncthreads();
-  int nzlo = s_misc[0], nzhi = s_misc[1];
-  if (nzlo >= nzhi) {  // no data at all: keep one (empty) group so that the run mirrors the reference
-    nzlo = 0;
-    nzhi = 0;
-  }
-  const int NB = (nzhi - nzlo + 63) / 64 > 0 ? (nzhi - nzlo + 63) / 64 : 1;
-
-  // epoch statics (every wave; only the role leaders and the M-step use them)
-  double t_e[NCH], tn_e[NCH], dt_e[NCH], lam_e[NCH];
-  bool vstat[NCH], ep_on[NCH];
-#pragma unroll
-  for (int c = 0; c < NCH; c++) {
-    const int e = c * kWave + lane;
-    ep_on[c] = e < E;
-    t_e[c] = s_t[e];
-    tn_e[c] = 0.0;
-    dt_e[c] = 0.0;
-    vstat[c] = false;
-    lam_e[c] = 0.0;
-    if (ep_on[c]) {
-      if (e < E - 1) {
-        tn_e[c] = s_t[e + 1];
-        dt_e[c] = tn_e[c] - t_e[c];
-        vstat[c] = (tn_e[c] != 0) && (dt_e[c] > 0);  // coal_EM.cpp:117
-      } else {
-        vstat[c] = true;
-      }
-      lam_e[c] = p.rates_in[(size_t)rep * p.rates_stride + e];
-    }
-  }
-  // bin statics: this lane's bin (compacted to the bins that carry data) and role
-  const int pos = grp * kWave + lane;  // position in the compacted tile
-  const int bin = nzlo + pos;
-  const bool in_range = (grp < NB) && (bin < nzhi);
-  double a_b = 0, cnt = 0, tk = 0, tkn = 0, dtk = 0, da = 0, db = 0;
-  int kb = E;
-  if (in_range) {
-    a_b = p.age_grid[bin];
-    cnt = s_cnt[role * APZ + bin];
-    kb = s_kb[bin];
-    tk = s_t[kb];
-    if (kb < E - 1) {
-      tkn = s_t[kb + 1];
-      dtk = tkn - tk;
-    }
-    da = a_b - tk;
-    db = tkn - a_b;
-  }
-  const bool live = in_range && cnt > 0;
-  const bool last_bin = (kb == E - 1);
-  // row-segmented reduction statics: f_d = 1 if the lane d to the left (same 16-lane row) is in
-  // the same epoch; a lane is the "tail" of its (row, epoch) run if its right neighbour is not
-  double f1 = 0, f2 = 0, f4 = 0, f8 = 0;
-  bool is_tail = false;
-  if (in_range) {
-    const int r = lane & 15;
-    if (r >= 1 && s_kb[bin - 1] == kb) f1 = 1.0;
-    if (r >= 2 && s_kb[bin - 2] == kb) f2 = 1.0;
-    if (r >= 4 && s_kb[bin - 4] == kb) f4 = 1.0;
-    if (r >= 8 && s_kb[bin - 8] == kb) f8 = 1.0;
-    is_tail = (r == 15) || (bin + 1 >= nzhi) || (s_kb[bin + 1] != kb);
-  }
-  const BinStat bs0{a_b, cnt, tk, tkn, dtk, da, db, f1, f2, f4, f8, kb, pos, live, last_bin, is_tail};
-  if (TPUT) {  // the same statics for every compacted position, packed (the bin phase rebuilds a BinStat per group)
-    for (int t = tid; t < AP; t += blockDim.x) {
-      const int b = nzlo + t;
-      int fl = 0;
-      if (t < NB * kWave && b < nzhi) {
-        const int k = s_kb[b], r = t & 15;
-        fl = BF_INRANGE | (k << BF_KB_SHIFT);
-        if (r >= 1 && s_kb[b - 1] == k) fl |= BF_F1;
-        if (r >= 2 && s_kb[b - 2] == k) fl |= BF_F2;
-        if (r >= 4 && s_kb[b - 4] == k) fl |= BF_F4;
-        if (r >= 8 && s_kb[b - 8] == k) fl |= BF_F8;
-        if (r == 15 || b + 1 >= nzhi || s_kb[b + 1] != k) fl |= BF_TAIL;
-      }
-      s_bflags[t] = fl;
-    }
-  }
-  // epoch-role statics: where the tails of this epoch sit in the compacted tile, and the counts of
-  // the bins in LATER epochs (this role's kind)
-  int slot0[NCH], slot1[NCH], slot2[NCH], row_x[NCH], row_hi[NCH], seg_hi[NCH];
-  double C0[NCH];
-  // The reference's denominators contain dt_e * integ with integ = 1 - num[0] - num[1] - ... (coal_EM.cpp:270-274,
-  // 445-449): where the mass still to coalesce is below the resolution of that subtraction (survival < ~1e-16:
-  // epochs behind a very high rate, or far older than all data) what remains is its rounding residue, which is
-  // >= 0 after the reference's clamps and averages kIntegResidue per unit count (measured on the reference:
-  // 2.7e-17 .. 5.7e-17, i.e. ~0.36 * 2^-53).  That residue is what drives the reference's rate to its floor in such
-  // epochs.  The factored sums below are exact there (mass 0), so the residue is put in explicitly: without it
-  // those epochs would get the ratio of two vanishing numbers instead of the reference's floor.
-  constexpr double kIntegResidue = 4.0e-17;
-  double c_all = 0.0;
-  for (int b = 0; b < A; b++) c_all += s_cnt[role * APZ + b];
-  double eta_e[NCH];  // dt_e * residue of this role's bins (0 in the last epoch, which has no dt_e * integ term)
-#pragma unroll
-  for (int c = 0; c < NCH; c++) eta_e[c] = dt_e[c] * (kIntegResidue * c_all);
-#pragma unroll
-  for (int c = 0; c < NCH; c++) {
-    const int e = c * kWave + lane;
-    int lo = A, hi = 0;
-    double c_later = 0.0;
-    if (ep_on[c]) {
-      for (int b = 0; b < A; b++) {
-        const int k = s_kb[b];
-        if (k == e) {
-          if (b < lo) lo = b;
-          hi = b + 1;
-        }
-        if (k > e) c_later += s_cnt[role * APZ + b];
-      }
-    }
-    C0[c] = c_later;
-    const int clo = (lo > nzlo ? lo : nzlo) - nzlo, chi = (hi < nzhi ? hi : nzhi) - nzlo;  // compacted, clipped
-    seg_hi[c] = chi;
-    slot0[c] = slot1[c] = slot2[c] = AP;  // a zero entry
-    row_x[c] = 1;
-    row_hi[c] = 0;
-    if (clo < chi) {
-      const int r0 = clo >> 4, r1 = (chi - 1) >> 4;
-      slot0[c] = (r0 * 16 + 15 < chi - 1) ? r0 * 16 + 15 : chi - 1;
-      if (r1 > r0) slot1[c] = ((r0 + 1) * 16 + 15 < chi - 1) ? (r0 + 1) * 16 + 15 : chi - 1;
-      if (r1 > r0 + 1) slot2[c] = ((r0 + 2) * 16 + 15 < chi - 1) ? (r0 + 2) * 16 + 15 : chi - 1;
-      row_x[c] = r0 + 3;  // rows beyond the first three (rare: an epoch spanning > 48 bins with data)
-      row_hi[c] = r1;
-    }
-  }
-  __syncthreads();
-  if (!TPUT && grp >= NB) return;  // waves without bins retire; later barriers count the remaining waves only
-  const bool leader = (grp == 0);
-  constexpr int erows = EROWS;  // 16-lane rows that hold epochs: a compile-time constant (skipping the cross-row
-                                // scan steps behind run-time uniform branches measured slower)
-  const int nwave_live = 2 * NB;
-  (void)nwave_live;
-
-  int my_flags = 0;
-  bool wrote_fail = false, flag_set = false;
-  const double thr = 1.0 - p.rel_tol;
-  double ll = -__builtin_inf(), prev_ll = -__builtin_inf();  // coal.cpp:3685
-  int iter = 0;
-  const int max_iter = (MODE == 1) ? 1 : p.max_iter;
-  double* out_mine = s_out + role * kNumBinArrays * APZ;
-
-#ifdef COLATE_EM_STAMPS
-  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long st_prev = stamp();
-#endif
-  for (iter = 0; iter < max_iter; iter++) {
-    COLATE_STAMP(7)
-    const bool need_ll = (MODE == 1) || (iter >= p.min_iter) || (iter == max_iter - 1);
-    // ============================================================ P1: epoch values (role leaders)
-    double q_e[NCH], p_e[NCH], beta_e[NCH], S_e[NCH], omS_e[NCH], cs_e[NCH], csn_e[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; c++) q_e[c] = p_e[c] = beta_e[c] = S_e[c] = omS_e[c] = cs_e[c] = csn_e[c] = 0.0;
-    if (leader && !COLATE_ABL_HAS(15)) {
-      double x_e[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; c++) x_e[c] = lam_e[c] * dt_e[c];
-      if (role == 0) {
-        // cs_e = sum_{j<e} lambda_j dt_j (coal_EM.cpp:100-103), as a wave scan
-        double carry = 0.0;
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-#if COLATE_ABL_HAS(11)
-          const double incl = x_e[c] * 7.0;
-#else
-          const double incl = wave_prefix_sum(x_e[c], erows);
-#endif
-          cs_e[c] = carry + dpp_d<WAVE_SHR1, 0xf, true>(0.0, incl);
-          csn_e[c] = cs_e[c] + x_e[c];
-          carry = carry + readlane_d(incl, 63);
-        }
-      }
-      COLATE_STAMP(8)
-      if (role == 0) {
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-          const int e = c * kWave + lane;
-#if COLATE_ABL_HAS(3)
-          S_e[c] = 1.0 - cs_e[c] * 1e-3;
-          omS_e[c] = cs_e[c] * 1e-3;
-#else
-          S_e[c] = em::em_exp_om(-cs_e[c], &omS_e[c]);  // omS = 1 - S_e = sum_{j<e} exp(A_ep[j])
-#endif
-          if (ep_on[c]) {
-            s_ep[G_CS * EPAD + e] = cs_e[c];
-            s_ep[G_S * EPAD + e] = S_e[c];
-            s_ep[G_PW * EPAD + e] = omS_e[c];
-          }
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-          const int e = c * kWave + lane;
-#if COLATE_ABL_HAS(7)
-          const double inv = 2.0e4 - lam_e[c];
-#else
-          const double inv = 1.0 / lam_e[c];
-#endif
-          const bool valid = vstat[c] && (lam_e[c] > 0);
-          if (e < E - 1) {
-            // exp(-cumsum[i+1] + cumsum[i]) of coal_EM.cpp:120, taken as exp(-lambda_e dt_e): the two arguments
-            // differ by the rounding of cumsum (<= ulp(cs)/2), and role B then needs no scan at all
-#if COLATE_ABL_HAS(4)
-            q_e[c] = 1.0 - x_e[c];
-#else
-            q_e[c] = em::em_exp(-x_e[c]);
-#endif
-            if (valid) {
-              p_e[c] = 1.0 - q_e[c];                                  // exp(A_ep + cs), coal_EM.cpp:119
-              beta_e[c] = (t_e[c] + inv) - (tn_e[c] + inv) * q_e[c];  // exp(B_ep + cs), coal_EM.cpp:120
-            }
-          } else if (e == E - 1 && valid) {  // last epoch, coal_EM.cpp:136-141
-            p_e[c] = 1.0;
-            beta_e[c] = t_e[c] + inv;
-          }
-          if (ep_on[c]) {
-            s_ep[G_LAM * EPAD + e] = lam_e[c];
-            s_ep[G_INV * EPAD + e] = inv;
-#if COLATE_ABL_HAS(7)
-            s_ep[G_XA * EPAD + e] = (t_e[c] + inv) * lam_e[c];
-#else
-            s_ep[G_XA * EPAD + e] = em::em_div_known_rcp(t_e[c] + inv, inv, lam_e[c]);  // (t + 1/lambda)/(1/lambda), coal_EM.cpp:204
-#endif
-            s_ep[G_P * EPAD + e] = p_e[c];
-            s_ep[G_BETA * EPAD + e] = beta_e[c];
-          }
-        }
-      }
-    }
-    COLATE_STAMP(9)
-    __syncthreads();  // ---- barrier 1: epoch values visible
-    COLATE_STAMP(0)
-    // the last epoch absorbs (lambda_{E-1} > 0) in every valid run; the reference asserts it only
-    // for bins inside the last epoch (coal_EM.cpp:351)
-    const double lam_last = s_ep[G_LAM * EPAD + E - 1];
-    const bool absorbing = lam_last > 0;
-    // ============================================================ P2: bin terms (own bins, own role)
-    auto bin_terms = [&](const BinStat& bs) {
-      const double a_b = bs.a_b, cnt = bs.cnt, tk = bs.tk, tkn = bs.tkn, dtk = bs.dtk, da = bs.da, db = bs.db;
-      const double f1 = bs.f1, f2 = bs.f2, f4 = bs.f4, f8 = bs.f8;
-      const int kb = bs.kb, pos = bs.pos;
-      const bool live = bs.live, last_bin = bs.last_bin, is_tail = bs.is_tail;
-      const int wslot = 2 * (pos >> 6) + role;  // entry of this (bin group, role) in s_fail / s_ll: the latency variant's wave
-      double o_w = 0, o_N = 0, o_D = 0, llp = 0.0;
-      bool fail = false;
-      if (live && !COLATE_ABL_HAS(12)) {
-        const double lk = s_ep[G_LAM * EPAD + kb], ik = s_ep[G_INV * EPAD + kb];
-        const bool lpos = lk > 0;
-        // -cumsum(age) at the merged grid (coal_EM.cpp:178-181): only the log-likelihood needs it
-        auto neg_cs_age = [&]() {
-          const double ck = s_ep[G_CS * EPAD + kb];
-          const double ck1 = ck + lk * da;
-          return -(ck1 + lk * (a_b - a_b));  // (second copy of `age` in the merged grid)
-        };
-        if (role == 0) {  // ---- EM_shared, coal_EM.cpp:198-210, 263-287
-          const double Sk = s_ep[G_S * EPAD + kb], Xak = s_ep[G_XA * EPAD + kb], PWk = s_ep[G_PW * EPAD + kb];
-#if COLATE_ABL_HAS(5)
-          const double qd = 1.0 - lk * da;
-#else
-          const double qd = em::em_exp(-(lk * da));  // exp(-cumsum(age) + cumsum(t_k)): same up to the rounding of cumsum
-#endif
-#if COLATE_ABL_HAS(8)
-          const double Y = (a_b + ik) * lk;
-#else
-          const double Y = em::em_div_known_rcp(a_b + ik, ik, lk);  // (age + 1/lambda)/(1/lambda), coal_EM.cpp:204
-#endif
-          const double Wp = lpos ? Sk * (1.0 - qd) : 0.0;
-          const double X = Xak - Y * qd;
-          const double Vp = lpos ? X * ik * Sk : 0.0;
-          const double Sig = PWk + Wp;
-          if (finite_pos(Sig)) {
-            const double r = em::em_rcp(Sig);
-            const double nk = Wp * r;
-            double dk = Vp * r + (-tk * nk);
-            dk = __builtin_fmax(dk, 0.0);
-            o_w = cnt * r;
-            o_N = cnt * nk;
-            o_D = cnt * dk;
-            if (need_ll) {
-              COLATE_COLD();
-              llp = cnt * em::em_log(Sig);
-            }
-          } else {
-            fail = true;
-          }
-        } else {  // ---- EM_notshared, coal_EM.cpp:330-357, 435-460
-          if (last_bin) {  // bin beyond the start of the last epoch, coal_EM.cpp:350-357
-            if (!lpos) my_flags |= COLATE_FLAG_NAN;  // reference: assert(coal_rate_e > 0)
-            double dk = (a_b + ik) - tk;
-            dk = __builtin_fmax(dk, 0.0);
-            o_N = cnt;
-            o_D = cnt * dk;
-            if (need_ll) {
-              COLATE_COLD();
-              llp = cnt * neg_cs_age();
-            }
-          } else {
-#if COLATE_ABL_HAS(6)
-            const double u = 1.0 - lk * db;
-#else
-            const double u = em::em_exp(-(lk * db));  // exp(-cumsum(t_{k+1}) + cumsum(age)), likewise
-#endif
-            const double pn = lpos ? 1.0 - u : 0.0;
-            const double bn = lpos ? (a_b + ik) - (tkn + ik) * u : 0.0;
-            if (absorbing) {  // normaliser = exp(-cs(age)) * ((1 - u) + u) = exp(-cs(age))
-              double dk = bn + (-tk * pn + dtk * (1.0 - pn));
-              dk = __builtin_fmax(dk, 0.0);
-              o_w = cnt * u;
-              o_N = cnt * pn;
-              o_D = cnt * dk;
-              if (need_ll) {
-                COLATE_COLD();
-                llp = cnt * neg_cs_age();
-              }
-            } else {  // last rate is 0: the mass beyond t_{k+1} is 1 - S_{E-1}/S_{k+1}
-              COLATE_COLD();
-              const double Gk1 = 1.0 - em::em_exp(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + kb + 1]);
-              const double SigN = pn + u * Gk1;
-              if (finite_pos(SigN)) {
-                const double rr = 1.0 / SigN;
-                const double nk = pn * rr;
-                double dk = bn * rr + (-tk * nk + dtk * (1.0 - nk));
-                dk = __builtin_fmax(dk, 0.0);
-                o_w = cnt * (u * rr);
-                o_N = cnt * nk;
-                o_D = cnt * dk;
-                llp = cnt * (neg_cs_age() + em::em_log(SigN));
-              } else {
-                fail = true;
-              }
-            }
-          }
-        }
-      }
-      COLATE_STAMP(1)
-      // bins whose normaliser failed (coal_EM.cpp:288-292, 461-465) drop out of the static counts
-      if (TPUT) {  // (a wave serves several groups: publish every time)
-        s_cfail[role * APZ + pos] = fail ? cnt : 0.0;
-        const bool any_fail = __any(fail);
-        if (lane == 0) s_fail[wslot] = any_fail ? 1 : 0;
-      } else {
-        const bool any_fail = __any(fail);
-        if (fail || wrote_fail) {  // publish, or clear what this lane published last time
-          COLATE_COLD();
-          s_cfail[role * APZ + pos] = fail ? cnt : 0.0;
-        }
-        wrote_fail = fail;
-        if (any_fail != flag_set) {  // (uniform) publish the per-wave flag only when it changes
-          COLATE_COLD();
-          if (lane == 0) s_fail[wslot] = any_fail ? 1 : 0;
-          flag_set = any_fail;
-        }
-      }
-      // sums over the run of equal-epoch bins inside each 16-lane row, left to right
-#define COLATE_SEG_STEP(CTRL, F)                              \
-  o_w = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_w), F, o_w);   \
-  o_N = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_N), F, o_N);   \
-  o_D = em::fma_(dpp_d<CTRL, 0xf, true>(0.0, o_D), F, o_D);
-#if !COLATE_ABL_HAS(2)  // ablation 2: no segmented reduce
-      COLATE_SEG_STEP(ROW_SHR1, f1)
-      COLATE_SEG_STEP(ROW_SHR2, f2)
-      COLATE_SEG_STEP(ROW_SHR4, f4)
-      COLATE_SEG_STEP(ROW_SHR8, f8)
-#endif
-#undef COLATE_SEG_STEP
-      if (is_tail) {
-        out_mine[O_W * APZ + pos] = o_w;
-        out_mine[O_N * APZ + pos] = o_N;
-        out_mine[O_D * APZ + pos] = o_D;
-      }
-      if (need_ll) {
-        COLATE_COLD();
-        const double tot = readlane_d(wave_prefix_sum(llp), 63);
-        if (lane == 0) s_ll[wslot] = tot;
-      }
-    };
-    if (TPUT) {
-      for (int g = 0; g < NB; g++) {  // this role's bin groups, one after the other
-        const int gpos = g * kWave + lane, fl = s_bflags[gpos], gbin = nzlo + gpos;
-        const bool inr = fl & BF_INRANGE;
-        BinStat b;
-        b.kb = inr ? (fl >> BF_KB_SHIFT) : 0;
-        b.pos = gpos;
-        b.a_b = inr ? s_age[gbin] : 0.0;
-        b.cnt = inr ? s_cnt[role * APZ + gbin] : 0.0;
-        b.tk = s_t[b.kb];
-        b.tkn = (b.kb < E - 1) ? s_t[b.kb + 1] : 0.0;
-        b.dtk = (b.kb < E - 1) ? b.tkn - b.tk : 0.0;
-        b.da = b.a_b - b.tk;
-        b.db = b.tkn - b.a_b;
-        b.f1 = (fl & BF_F1) ? 1.0 : 0.0;
-        b.f2 = (fl & BF_F2) ? 1.0 : 0.0;
-        b.f4 = (fl & BF_F4) ? 1.0 : 0.0;
-        b.f8 = (fl & BF_F8) ? 1.0 : 0.0;
-        b.live = inr && b.cnt > 0;
-        b.last_bin = (b.kb == E - 1);
-        b.is_tail = fl & BF_TAIL;
-        bin_terms(b);
-      }
-    } else {
-      bin_terms(bs0);
-    }
-    COLATE_STAMP(2)
-    __syncthreads();  // ---- barrier 2: per-bin tails visible
-    COLATE_STAMP(3)
-    // ============================================================ P3: per-epoch sums (role leaders)
-    if (leader && !COLATE_ABL_HAS(13)) {
-      // did a bin of this role fail this iteration? (entries of retired waves stay 0; loaded with the
-      // tails: one LDS wait; fixed count -- a runtime-bounded loop here compiles to a vectorised monster)
-      const int anyf = s_fail[role] | s_fail[2 + role] | s_fail[4 + role] | s_fail[6 + role];
-      double w[NCH], oN[NCH], oD[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; c++) {
-#if COLATE_ABL_HAS(1)  // ablation: no tail loads
-        const double w0 = 1e-3 * lane, w1 = 0, w2 = 0, n0 = 1e-3, n1 = 0, n2 = 0, d0 = 1.0, d1 = 0, d2 = 0;
-#else
-        const double w0 = out_mine[O_W * APZ + slot0[c]], w1 = out_mine[O_W * APZ + slot1[c]], w2 = out_mine[O_W * APZ + slot2[c]];
-        const double n0 = out_mine[O_N * APZ + slot0[c]], n1 = out_mine[O_N * APZ + slot1[c]], n2 = out_mine[O_N * APZ + slot2[c]];
-        const double d0 = out_mine[O_D * APZ + slot0[c]], d1 = out_mine[O_D * APZ + slot1[c]], d2 = out_mine[O_D * APZ + slot2[c]];
-#endif
-        if (role == 0) {  // the shared leader also needs the not-shared leader's p_e, beta_e
-          p_e[c] = s_ep[G_P * EPAD + c * kWave + lane];
-          beta_e[c] = s_ep[G_BETA * EPAD + c * kWave + lane];
-        }
-        w[c] = (w0 + w1) + w2;
-        oN[c] = (n0 + n1) + n2;
-        oD[c] = ((d0 + d1) + d2) + eta_e[c];  // (the residue joins the own-epoch sum: off the scan's dependency chain)
-        for (int r = row_x[c]; r <= row_hi[c]; r++) {
-          COLATE_COLD();
-          int slot = r * 16 + 15;
-          if (slot > seg_hi[c] - 1) slot = seg_hi[c] - 1;
-          w[c] += out_mine[O_W * APZ + slot];
-          oN[c] += out_mine[O_N * APZ + slot];
-          oD[c] += out_mine[O_D * APZ + slot];
-        }
-      }
-      COLATE_STAMP(10)
-      // counts of this role's bins in LATER epochs, minus those whose normaliser failed this iteration
-      double Cn[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; c++) Cn[c] = C0[c];
-      {
-        if (anyf) {
-          COLATE_COLD();
-#pragma unroll
-          for (int c = 0; c < NCH; c++) {
-            double fs = 0.0;
-            for (int q = seg_hi[c] > 0 ? seg_hi[c] : 0; ep_on[c] && q < nzhi - nzlo; q++) {
-              if (s_kb[nzlo + q] > c * kWave + lane) fs += s_cfail[role * APZ + q];
-            }
-            Cn[c] -= fs;
-          }
-        }
-      }
-      double Npart[NCH], Dpart[NCH];
-      if (role == 0) {
-        // RS = sum c r over the shared bins of LATER epochs (suffix sums over epochs)
-        double RSn[NCH];
-        double cR = 0.0;
-#pragma unroll
-        for (int c = NCH - 1; c >= 0; c--) {
-#if COLATE_ABL_HAS(9)
-          const double sR = w[c] * 3.0;
-#else
-          const double sR = wave_suffix_sum(w[c], lane, erows);
-#endif
-          RSn[c] = cR + dpp_d<WAVE_SHL1, 0xf, true>(0.0, sR);
-          cR = cR + readlane_d(sR, 0);
-        }
-        COLATE_STAMP(11)
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-          const int e = c * kWave + lane;
-          const double W = S_e[c] * p_e[c];                    // exp(A_ep)
-          const double VW = S_e[c] * beta_e[c] - t_e[c] * W;   // exp(B_ep) - t_e exp(A_ep)
-          const double PWn = omS_e[c] + W;                     // sum_{j<=e} exp(A_ep[j])
-          Npart[c] = W * RSn[c] + oN[c];
-          if (e < E - 1) {
-            // sum_b c_b (exp(B_e - Z_b) - t_e num_e(b) + dt_e integ_e(b)) over the shared bins of later epochs;
-            // the reference clamps every bin's term at 0 (coal_EM.cpp:277), here the (non-negative) sums are
-            double integ = Cn[c] - PWn * RSn[c];  // sum_b c_b (1 - r_b PW_{e+1})
-            integ = __builtin_fmax(integ, 0.0);
-            double dsh = VW * RSn[c] + dt_e[c] * integ;
-            dsh = __builtin_fmax(dsh, 0.0);
-            Dpart[c] = dsh + oD[c];
-          } else {
-            Dpart[c] = oD[c];
-          }
-        }
-      } else {
-        // forward recurrence T_{e+1} = q_e T_e + h_e, T_0 = 0
-        // (T_e = sum over not-shared bins b in EARLIER epochs of c_b u_b/Sig_b * S_e/S_{k_b+1})
-        double T[NCH];
-        double Tc = 0.0;
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-          double a = ep_on[c] ? q_e[c] : 1.0, b = ep_on[c] ? w[c] : 0.0;
-#if !COLATE_ABL_HAS(9)
-          wave_affine_scan(a, b, erows);
-#endif
-          const double Tn = em::fma_(a, Tc, b);         // T_{e+1}
-          T[c] = dpp_d<WAVE_SHR1, 0xf, false>(Tc, Tn);  // T_e (lane 0: carry-in)
-          Tc = readlane_d(Tn, 63);
-        }
-        COLATE_STAMP(12)
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-          const int e = c * kWave + lane;
-          Npart[c] = p_e[c] * T[c] + oN[c];
-          if (e < E - 1) {
-            double Gn = 1.0;  // mass still to coalesce after t_{e+1}, relative to survival there
-            if (!absorbing) {
-              COLATE_COLD();
-              Gn = 1.0 - em::em_exp(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + e + 1]);
-            }
-            // later not-shared bins contribute dt_e each, earlier ones their tail mass
-            double dns = dt_e[c] * Cn[c] + ((beta_e[c] - t_e[c] * p_e[c]) * T[c] + dt_e[c] * Gn * (q_e[c] * T[c]));
-            dns = __builtin_fmax(dns, 0.0);
-            Dpart[c] = dns + oD[c];
-          } else {
-            double dns = (beta_e[c] - t_e[c] * p_e[c]) * T[c];
-            dns = __builtin_fmax(dns, 0.0);
-            Dpart[c] = dns + oD[c];
-          }
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < NCH; c++) {
-        if (ep_on[c]) {
-          s_nd[(role * 2 + 0) * EPAD + c * kWave + lane] = Npart[c];
-          s_nd[(role * 2 + 1) * EPAD + c * kWave + lane] = Dpart[c];
-        }
-      }
-    }
-    COLATE_STAMP(4)
-    __syncthreads();  // ---- barrier 3: partial N, D visible
-    // ============================================================ P4: M-step (every wave) and stop rule
-    double N_e[NCH], D_e[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      const int e = c * kWave + lane;
-      N_e[c] = s_nd[0 * EPAD + e] + s_nd[2 * EPAD + e];
-      D_e[c] = s_nd[1 * EPAD + e] + s_nd[3 * EPAD + e];
-      if (MODE == 1 && ep_on[c]) {  // (EM mode: a NaN sticks to the rate and is flagged at the end)
-        if (N_e[c] != N_e[c] || D_e[c] != D_e[c]) my_flags |= COLATE_FLAG_NAN;  // coal.cpp:3711-3712
-        if (N_e[c] < 0.0 || D_e[c] < 0.0) my_flags |= COLATE_FLAG_NEG;          // coal.cpp:3713-3714
-      }
-    }
-    if (need_ll) {
-      COLATE_COLD();
-      ll = ((s_ll[0] + s_ll[1]) + (s_ll[2] + s_ll[3])) + ((s_ll[4] + s_ll[5]) + (s_ll[6] + s_ll[7]));  // retired waves: 0
-    }
-    if (MODE == 1) {
-      if (wave == 0) {
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-          if (ep_on[c]) {
-            p.out_num[(size_t)rep * E + c * kWave + lane] = N_e[c];
-            p.out_den[(size_t)rep * E + c * kWave + lane] = D_e[c];
-          }
-        }
-      }
-      break;
-    }
-    // ---- M-step, coal.cpp:3777-3804
-    if (!COLATE_ABL_HAS(14)) {
-      double cand[NCH];
-      unsigned long long keep[NCH];  // epochs that do NOT copy their predecessor
-      bool simple = true;            // the copying epochs form a prefix 0..m-1: they all become 0
-      bool lower_keep = false;
-#pragma unroll
-      for (int c = 0; c < NCH; c++) {
-        const bool copy = (N_e[c] == 0);
-        cand[c] = lam_e[c];
-        if (!copy && D_e[c] != 0) {
-#if COLATE_ABL_HAS(10)
-          cand[c] = N_e[c] * 1e-4 + D_e[c] * 1e-9;
-#else
-          cand[c] = N_e[c] / D_e[c];
-#endif
-          if (cand[c] < p.rate_floor) cand[c] = p.rate_floor;
-        }
-        keep[c] = __ballot(ep_on[c] && !copy);
-        const unsigned long long cp = __ballot(ep_on[c] && copy);
-        if (cp && (lower_keep || (cp & (cp + 1ull)))) simple = false;
-        if (keep[c]) lower_keep = true;
-      }
-      if (simple) {
-#pragma unroll
-        for (int c = 0; c < NCH; c++) lam_e[c] = ((keep[c] >> lane) & 1ull) ? cand[c] : 0.0;
-      } else {
-        COLATE_COLD();
-        // num == 0: take the (already updated) rate of the previous epoch, 0 if there is none
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-          const unsigned long long below = keep[c] & ((1ull << lane) - 1ull);
-          const int src = below ? 63 - __builtin_clzll(below) : 0;
-          const double from_chunk = __shfl(cand[c], src, 64);
-          double from_lower = 0.0;  // nearest keeper in an earlier chunk (uniform)
-          bool have_lower = false;
-#pragma unroll
-          for (int cc = NCH - 1; cc >= 0; cc--) {
-            if (cc < c && !have_lower && keep[cc]) {
-              from_lower = readlane_d(cand[cc], 63 - __builtin_clzll(keep[cc]));
-              have_lower = true;
-            }
-          }
-          const bool self = (keep[c] >> lane) & 1ull;
-          lam_e[c] = ep_on[c] ? (self ? cand[c] : (below ? from_chunk : from_lower)) : 0.0;
-        }
-      }
-    }
-    COLATE_STAMP(5)
-    // stop rule, coal.cpp:3822 (evaluated after the update); uniform across the workgroup
-    bool stop = false;
-    if (iter > p.min_iter) {
-      COLATE_COLD();
-      stop = (ll / prev_ll > thr);
-    }
-    prev_ll = ll;
-    if (stop) break;
-  }
-
-#ifdef COLATE_EM_STAMPS
-  if (p.out_num && lane == 0 && MODE == 0 && leader) {  // diagnostic build: per-role phase cycles in place of out_num
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out_num) + ((size_t)rep * 4 + role) * 16;
-    for (int i = 0; i < 16; i++) dbg[i] = st_acc[i];
-  }
-#endif
-#ifdef COLATE_EM_TRACE
-  if (p.out_num && tid == 0 && MODE == 0) {
-    unsigned long long trace_t1;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trace_t1)::"memory");
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out_num) + (size_t)rep * 4;
-    dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
-    dbg[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
-    dbg[2] = trace_t0;
-    dbg[3] = trace_t1;
-  }
-#endif
-  // ------------------------------------------------------------------ epilogue
-  if (MODE == 0 && wave == 0) {
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      if (ep_on[c]) {
-        if (lam_e[c] != lam_e[c]) my_flags |= COLATE_FLAG_NAN;
-        p.out_rates[(size_t)rep * E + c * kWave + lane] = lam_e[c];
-      }
-    }
-  }
-  if (my_flags) atomicOr(&s_misc[2], my_flags);
-  __syncthreads();
-  if (tid == 0) {
-    int fl = s_misc[2];
-    if (MODE == 0) {
-      if (iter >= p.max_iter) fl |= COLATE_FLAG_MAXITER;
-      p.out_iters[rep] = iter < p.max_iter ? iter : p.max_iter;
-    }
-    p.out_ll[rep] = ll;
-    p.out_flags[rep] = fl;
-  }
-}
-
-template <int MODE, int NCH, int EROWS, bool TPUT>
-hipError_t launch_one(const ColateEmArgs& args, hipStream_t stream, size_t lds, int threads) {
-  auto kern = em_kernel<MODE, NCH, EROWS, TPUT>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL(kern, dim3(args.B), dim3(threads), lds, stream, args);
-  return hipGetLastError();
-}
-
-}  // namespace
-
-static int em_groups(int A) { return (A + 63) / 64; }           // bin groups of 64 per role
-static int em_threads(int A) { return 2 * 64 * em_groups(A); }  // two roles (latency variant)
-static int em_chunks(int E) { return E <= 64 ? 1 : (E <= 128 ? 2 : 4); }
-
-size_t colate_em_lds_bytes(int E, int A) {
-  const size_t EPAD = (size_t)em_chunks(E) * kWave;
-  const size_t AP = (size_t)em_groups(A) * kWave;
-  const size_t APZ = AP + 16;
-  const size_t doubles = (EPAD + 1) + kNumGather * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ + 8 + AP;
-  const size_t ints = (AP + 1) + 8 + 4 + AP;
-  return doubles * sizeof(double) + ints * sizeof(int);
-}
+size_t colate_em_lds_bytes(int E, int A) { return em_lds_bytes(E, A); }
 
 // number of CUs of the current device (cached per ordinal)
 static int device_cus() {
@@ -965,39 +27,38 @@ static int device_cus() {
   return cus[dev] > 0 ? cus[dev] : 0;
 }
 
-// The throughput variant pays off once the latency variant would leave workgroups waiting for a CU (it holds
-// two per CU).  COLATE_EM_VARIANT=latency|throughput overrides the choice (tests, experiments).
-static bool use_throughput_variant(const ColateEmArgs& args) {
-  if (args.mode != 0 || em_chunks(args.E) > 2) return false;
+// 0 = latency (max-ilp build), 1 = latency (default build), 2 = throughput.
+// COLATE_EM_VARIANT=latency|latency-ilp|throughput overrides the choice for E <= 128 (tests, experiments).
+int colate_em_variant(int B, int E) {
+  if (em_chunks(E) > 2) return 2;  // 129..256 epochs: only the two-wave layout fits the register file without scratch
   if (const char* v = getenv("COLATE_EM_VARIANT")) {
-    if (!strcmp(v, "throughput")) return true;
-    if (!strcmp(v, "latency")) return false;
+    if (!strcmp(v, "throughput")) return 2;
+    if (!strcmp(v, "latency")) return 1;
+    if (!strcmp(v, "latency-ilp")) return 0;
   }
   const int cus = device_cus();
-  return cus > 0 && args.B > 2 * cus;
+  if (cus <= 0 || B <= cus) return 0;
+  return B <= 2 * cus ? 1 : 2;
 }
 
 hipError_t colate_em_launch(const ColateEmArgs& args, hipStream_t stream) {
-  const size_t lds = colate_em_lds_bytes(args.E, args.A);
-  const int threads = em_threads(args.A);
+  const size_t lds = em_lds_bytes(args.E, args.A);
   const int nch = em_chunks(args.E);
-  const int rows = args.E <= 16 ? 1 : (args.E <= 32 ? 2 : 4);  // BASELINE's `--bins 3,7,0.2` gives E = 23
   if (args.mode == 1) {
+    const int threads = em_threads(args.A);
     if (nch == 1) return launch_one<1, 1, 4, false>(args, stream, lds, threads);
     if (nch == 2) return launch_one<1, 2, 4, false>(args, stream, lds, threads);
     return launch_one<1, 4, 4, false>(args, stream, lds, threads);
   }
-  if (use_throughput_variant(args)) {
-    if (nch == 2) return launch_one<0, 2, 4, true>(args, stream, lds, 2 * kWave);
-    if (rows == 1) return launch_one<0, 1, 1, true>(args, stream, lds, 2 * kWave);
-    if (rows == 2) return launch_one<0, 1, 2, true>(args, stream, lds, 2 * kWave);
-    return launch_one<0, 1, 4, true>(args, stream, lds, 2 * kWave);
+  switch (colate_em_variant(args.B, args.E)) {
+    case 0: return colate_em_launch_latency_ilp(args, stream);
+    case 1: return launch_latency(args, stream);
   }
-  if (nch == 1) {
-    if (rows == 1) return launch_one<0, 1, 1, false>(args, stream, lds, threads);
-    if (rows == 2) return launch_one<0, 1, 2, false>(args, stream, lds, threads);
-    return launch_one<0, 1, 4, false>(args, stream, lds, threads);
+  if (nch == 4) return launch_one<0, 4, 4, true>(args, stream, lds, 2 * kWave);
+  if (nch == 2) return launch_one<0, 2, 4, true>(args, stream, lds, 2 * kWave);
+  switch (em_rows(args.E)) {
+    case 1: return launch_one<0, 1, 1, true>(args, stream, lds, 2 * kWave);
+    case 2: return launch_one<0, 1, 2, true>(args, stream, lds, 2 * kWave);
+    default: return launch_one<0, 1, 4, true>(args, stream, lds, 2 * kWave);
   }
-  if (nch == 2) return launch_one<0, 2, 4, false>(args, stream, lds, threads);
-  return launch_one<0, 4, 4, false>(args, stream, lds, threads);
 }

@@ -9,6 +9,7 @@
 // Everything here runs once per invocation on the host; the per-replicate EM,
 // which is where the reference spends its time, is the HIP kernel.
 #include <sys/resource.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -36,7 +37,8 @@ namespace {
 // Same option names as Colate.cpp:11-45 (unknown options are an error there too:
 // cxxopts throws option_not_exists_exception).  `--num_bootstrap` (README spelling)
 // is accepted as an alias of `--num_bootstraps`.  Ours: `--device N` (GPU ordinal), `--devices N`
-// (shard the replicates over GPUs 0..N-1 of the node),
+// (shard the replicates over GPUs 0..N-1 of the node from this one process), `--ranks N` (the same sharding as N
+// processes, one per GPU, with one RCCL all-gather of the results: run_ranked below),
 // `--counts_out FILE` (write the bootstrap count tables in the reference's .colate_mat layout,
 // 17 significant digits) and `--counts_only` (stop after that; needs no GPU).
 struct Options {
@@ -50,7 +52,7 @@ const char* const kValueOptions[] = {
     "target_table", "target_bam", "reference_bam", "target_tmp", "reference_tmp", "target_age",
     "reference_age", "ref_genome", "anc_genome", "mask", "mask_cutoff", "chr", "bins",
     "lineage_bin", "outgroup_tmrca", "years_per_gen", "coal", "seed", "num_bootstraps", "filters",
-    "groups", "poplabels", "map", "input", "output", "device", "devices", "counts_out", "pairs"};
+    "groups", "poplabels", "map", "input", "output", "device", "devices", "ranks", "counts_out", "pairs"};
 const char* const kBoolOptions[] = {"help", "strandfilter", "counts_only"};
 
 bool parse_options(int argc, char** argv, Options& o, std::string& err) {
@@ -118,7 +120,8 @@ void print_help() {
             << "      --seed arg             Optional: Seed for random number generator (int)\n"
             << "      --num_bootstraps arg   Optional: Number of bootstraps.\n"
             << "      --device arg           Optional (colate_amd): GPU ordinal, default 0.\n"
-            << "      --devices arg          Optional (colate_amd): shard the bootstrap replicates over GPUs 0..N-1.\n"
+            << "      --devices arg          Optional (colate_amd): shard the bootstrap replicates over GPUs 0..N-1 (one process).\n"
+            << "      --ranks arg            Optional (colate_amd): the same as N processes, one per GPU, one RCCL all-gather.\n"
             << "      --pairs arg            Optional (colate_amd): file of `target_tmp reference_tmp output [target_age reference_age]`\n"
             << "                             lines; all pairs share --mut/--chr/--bins/--num_bootstraps/--seed, each .mut is parsed\n"
             << "                             once and all replicates of all pairs run in one GPU launch.\n"
@@ -468,6 +471,35 @@ bool file_exists(const std::string& p) {
 void write_counts_file(const std::string& path, int B, int A, const std::vector<double>& grid,
                        const double* csh, const double* cns);
 
+// `--ranks N`: this process is rank `rank` of `nranks` (run_ranked forks them); the 128-byte RCCL id travels from
+// rank 0 to the others through the launcher's pipes.
+struct RankCtx {
+  bool ranked = false;  // launched by run_ranked (also with one rank: the RCCL path with a communicator of one)
+  int rank = 0, nranks = 1;
+  int fd_id_out = -1;  // rank 0: writes the id here
+  int fd_id_in = -1;   // ranks > 0: read it here
+};
+RankCtx g_rank;
+
+bool write_all(int fd, const void* buf, size_t n) {
+  const char* p = static_cast<const char*>(buf);
+  while (n) {
+    ssize_t k = ::write(fd, p, n);
+    if (k <= 0) return false;
+    p += k, n -= (size_t)k;
+  }
+  return true;
+}
+bool read_all(int fd, void* buf, size_t n) {
+  char* p = static_cast<char*>(buf);
+  while (n) {
+    ssize_t k = ::read(fd, p, n);
+    if (k <= 0) return false;
+    p += k, n -= (size_t)k;
+  }
+  return true;
+}
+
 int run_mut(const Options& opt) {
   if (!opt.has("mut") || !opt.has("output")) {  // coal.cpp:3077-3087
     std::cout << "Not enough arguments supplied." << std::endl;
@@ -566,7 +598,7 @@ int run_mut(const Options& opt) {
     // the weights come from the run's mt19937 either way (coal.cpp:3350-3357); the weighted sums and
     // the F redistribution run on the GPU together with the EM unless only the counts are wanted
     // (--counts_only, no device needed) or the replicates are sharded over several GPUs
-    gpu_bootstrap = !opt.has("counts_only") && !opt.has("devices");
+    gpu_bootstrap = !opt.has("counts_only") && !opt.has("devices") && !(g_rank.ranked && opt.has("counts_out"));
     if (gpu_bootstrap) {
       weights.resize((size_t)B * nb);
       if (int rc = colate_bootstrap_weights(&rng, B, nb, weights.data())) {
@@ -589,7 +621,7 @@ int run_mut(const Options& opt) {
     write_counts_file(opt.get("counts_out"), B, A, age_grid, csh.data(), cns.data());
   };
   if (opt.has("counts_out") && !gpu_bootstrap) {
-    write_counts();
+    if (g_rank.rank == 0) write_counts();
     if (opt.has("counts_only")) return 0;
   }
 
@@ -616,7 +648,7 @@ int run_mut(const Options& opt) {
   init_rates.resize(E);
 
   std::cerr << "Maximising likelihood using EM.. " << std::endl;
-  if (opt.has("device")) {
+  if (opt.has("device") && !g_rank.ranked) {
     if (int rc = colate_set_device(std::stoi(opt.get("device")))) {
       std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
       return 1;
@@ -625,7 +657,48 @@ int run_mut(const Options& opt) {
   std::vector<double> rates((size_t)B * E), ll(B);
   std::vector<int> iters(B), flags(B);
   int rc;
-  if (opt.has("devices")) {
+  if (g_rank.ranked) {
+    // one process per GPU: this rank's contiguous replicate range on its own device, then ONE RCCL all-gather
+    const int ndev = colate_device_count();
+    if (ndev < 1) {
+      std::cerr << "Error: " << colate_last_error() << std::endl;
+      return 1;
+    }
+    const int dev0 = opt.has("device") ? std::stoi(opt.get("device")) : 0;
+    unsigned char id[COLATE_COMM_ID_BYTES];
+    void* comm = nullptr;
+    rc = colate_set_device((dev0 + g_rank.rank) % ndev);
+    if (!rc) {
+      if (g_rank.rank == 0) {
+        rc = colate_comm_unique_id(id);
+        if (!write_all(g_rank.fd_id_out, id, rc ? 0 : sizeof(id)) && !rc) rc = COLATE_EIO;
+        ::close(g_rank.fd_id_out);  // (on failure the launcher sees end-of-file and tells the others)
+      } else if (!read_all(g_rank.fd_id_in, id, sizeof(id))) {
+        std::cerr << "Error: rank " << g_rank.rank << " did not receive the communicator id." << std::endl;
+        return 1;
+      }
+    }
+    if (!rc) rc = colate_comm_create(id, g_rank.nranks, g_rank.rank, &comm);
+    if (!rc) {
+      if (gpu_bootstrap)
+        rc = colate_bootstrap_em_batch_allgather(comm, B, num_blocks, E, A, age_grid.data(), age, weights.data(), fsh.data(),
+                                                 fns.data(), fshe.data(), fnse.data(), epochs.data(), init_rates.data(),
+                                                 COLATE_DEFAULT_MAX_ITER, COLATE_DEFAULT_MIN_ITER, COLATE_DEFAULT_REL_TOL,
+                                                 COLATE_DEFAULT_RATE_FLOOR, rates.data(), iters.data(), ll.data(), flags.data());
+      else
+        rc = colate_em_batch_allgather(comm, B, E, A, age_grid.data(), csh.data(), cns.data(), epochs.data(),
+                                       init_rates.data(), COLATE_DEFAULT_MAX_ITER, COLATE_DEFAULT_MIN_ITER,
+                                       COLATE_DEFAULT_REL_TOL, COLATE_DEFAULT_RATE_FLOOR, rates.data(), iters.data(),
+                                       ll.data(), flags.data());
+    }
+    std::string msg = rc ? colate_last_error() : "";
+    colate_comm_destroy(comm);
+    if (rc) {
+      std::cerr << "Error: " << msg << " (" << rc << ")" << std::endl;
+      return 1;
+    }
+    if (g_rank.rank != 0) return 0;  // every rank holds all results; rank 0 reports and writes them
+  } else if (opt.has("devices")) {
     const int nd = std::stoi(opt.get("devices"));
     if (nd < 1) {
       std::cerr << "Error: --devices must be at least 1." << std::endl;
@@ -653,13 +726,19 @@ int run_mut(const Options& opt) {
     std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
     return 1;
   }
+  int unresolved_max = 0;
   for (int i = 0; i < B; i++) {
     std::cerr << "Bootstrap " << i + 1 << ": Total iterations " << iters[i] << std::endl;
     if (flags[i] & (COLATE_FLAG_NAN | COLATE_FLAG_NEG))
       std::cerr << "Warning: bootstrap " << i + 1
                 << " produced NaN or negative sufficient statistics (the reference aborts here)."
                 << std::endl;
+    unresolved_max = std::max(unresolved_max, COLATE_UNRESOLVED_EPOCHS(flags[i]));
   }
+  if (unresolved_max > 0)  // (include/colate_amd.h, COLATE_FLAG_UNRESOLVED)
+    std::cerr << "Note: the last " << unresolved_max << " of " << E << " epochs are older than the data resolve: "
+              << "their printed rates depend on rounding residue (in the reference build too) and are not reproducible."
+              << std::endl;
   if (colate_write_coal((out + ".coal").c_str(), B, E, epochs.data(), rates.data(), is_ancient ? 1 : 0, ep_null)) {
     std::cerr << "Error: " << colate_last_error() << std::endl;
     return 1;
@@ -871,6 +950,91 @@ int run_mut_pairs(const Options& opt) {
   return 0;
 }
 
+// `--ranks N`: fork N processes BEFORE anything touches the GPU (this process never does), one per GPU; each runs the
+// whole `--mode mut` pipeline (same inputs, same --seed, hence the same tables and bootstrap weights), computes its
+// contiguous range of replicates and takes part in one RCCL all-gather (colate_comm.cpp); rank 0 writes the outputs.
+// The launcher only relays rank 0's 128-byte communicator id to the other ranks and collects the exit codes.
+int run_ranked(const Options& opt, int nranks) {
+  if (!opt.has("seed")) {
+    std::cerr << "Error: --ranks needs --seed (every rank must draw the same bootstrap weights)." << std::endl;
+    return 1;
+  }
+  if (opt.has("pairs") || opt.has("devices")) {
+    std::cerr << "Error: --ranks cannot be combined with --pairs or --devices." << std::endl;
+    return 1;
+  }
+  int up[2];
+  if (::pipe(up) != 0) {
+    std::perror("pipe");
+    return 1;
+  }
+  std::vector<int> down_r(nranks, -1), down_w(nranks, -1);
+  for (int r = 1; r < nranks; r++) {
+    int fd[2];
+    if (::pipe(fd) != 0) {
+      std::perror("pipe");
+      return 1;
+    }
+    down_r[r] = fd[0], down_w[r] = fd[1];
+  }
+  std::cerr.flush();
+  std::cout.flush();
+  std::vector<pid_t> pids(nranks, -1);
+  for (int r = 0; r < nranks; r++) {
+    pid_t pid = ::fork();
+    if (pid < 0) {
+      std::perror("fork");
+      return 1;
+    }
+    if (pid == 0) {  // rank r
+      g_rank.ranked = true, g_rank.rank = r, g_rank.nranks = nranks;
+      ::close(up[0]);
+      for (int q = 1; q < nranks; q++) {
+        ::close(down_w[q]);
+        if (q != r) ::close(down_r[q]);
+      }
+      if (r == 0) {
+        g_rank.fd_id_out = up[1];
+      } else {
+        ::close(up[1]);
+        g_rank.fd_id_in = down_r[r];
+        // only rank 0 talks on the terminal; the others keep their progress lines in a file that a clean exit removes
+        const std::string log = opt.get("output") + ".rank" + std::to_string(r) + ".stderr";
+        if (!std::freopen(log.c_str(), "w", stderr)) std::perror("freopen");
+      }
+      int code = 1;
+      try {
+        code = run_mut(opt);
+      } catch (const std::exception& e) {
+        std::cerr << "Error: " << e.what() << std::endl;
+      }
+      std::cerr.flush();
+      if (r != 0 && code == 0) std::remove((opt.get("output") + ".rank" + std::to_string(r) + ".stderr").c_str());
+      std::fflush(nullptr);
+      ::_exit(code);
+    }
+    pids[r] = pid;
+  }
+  ::close(up[1]);
+  for (int r = 1; r < nranks; r++) ::close(down_r[r]);
+  unsigned char id[COLATE_COMM_ID_BYTES];
+  if (read_all(up[0], id, sizeof(id)))  // else rank 0 failed first: closing the pipes below releases the others
+    for (int r = 1; r < nranks; r++) write_all(down_w[r], id, sizeof(id));
+  ::close(up[0]);
+  for (int r = 1; r < nranks; r++) ::close(down_w[r]);
+  int worst = 0;
+  for (int r = 0; r < nranks; r++) {
+    int st = 0;
+    if (::waitpid(pids[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+      std::cerr << "Error: rank " << r << " failed";
+      if (r > 0) std::cerr << " (see " << opt.get("output") << ".rank" << r << ".stderr)";
+      std::cerr << std::endl;
+      worst = 1;
+    }
+  }
+  return worst;
+}
+
 }  // namespace
 
 extern "C" int colate_mut_main(int argc, char** argv) {
@@ -893,6 +1057,14 @@ extern "C" int colate_mut_main(int argc, char** argv) {
       return 0;
     }
     try {
+      if (opt.has("ranks")) {
+        const int nranks = std::stoi(opt.get("ranks"));
+        if (nranks < 1 || nranks > 64) {
+          std::cerr << "Error: --ranks must be between 1 and 64." << std::endl;
+          return 1;
+        }
+        if (opt.has("mut") && opt.has("output")) return run_ranked(opt, nranks);  // (also for N = 1: same code path)
+      }
       if (opt.has("pairs")) return run_mut_pairs(opt);
       return run_mut(opt);
     } catch (const std::exception& e) {

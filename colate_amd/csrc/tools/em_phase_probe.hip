@@ -7,6 +7,7 @@
 #define COLATE_EM_STAMPS 1
 #endif
 #include "../em_kernels.hip"
+#include "../em_kernels_ilp.hip"  // (same template again: the probe builds one translation unit)
 
 #include <cmath>
 #include <cstdio>

@@ -5,6 +5,7 @@
 //   residency_probe [replicates] [age_bins]
 #define COLATE_EM_TRACE 1
 #include "../em_kernels.hip"
+#include "../em_kernels_ilp.hip"  // (same template again: the probe builds one translation unit)
 
 #include <algorithm>
 #include <cmath>

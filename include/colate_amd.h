@@ -41,6 +41,17 @@ extern "C" {
 #define COLATE_FLAG_NAN 1
 #define COLATE_FLAG_NEG 2
 #define COLATE_FLAG_MAXITER 4
+/* Not an error: the last COLATE_UNRESOLVED_EPOCHS(flags) epochs of this replicate are below the resolution of the
+ * reference's own arithmetic -- the survival probability there is so small that the `integ` term of its denominators
+ * (coal_EM.cpp:270-274, 445-449) is rounding residue, and the reference's printed rate changes by more than 1e-8
+ * (relative; by orders of magnitude a few epochs further on) when its libm's exp()/log() return a neighbouring double.
+ * Rates of such epochs are returned (deep in that regime they are the floor, as in the reference) but are outside the
+ * 1e-6 parity claim; all other epochs are inside it.  out_flags == 0 therefore still means: clean and fully
+ * reproducible.  With --bins 3,7,0.2 (23 epochs) no epoch is ever unresolved on whole-genome tables; with
+ * --bins 2,7.95,0.05 (122 epochs) the last ~17 are (profiles/parity/). */
+#define COLATE_FLAG_UNRESOLVED 8
+#define COLATE_STATUS_FLAGS(flags) ((flags) & 0xff)
+#define COLATE_UNRESOLVED_EPOCHS(flags) ((int)((unsigned)(flags) >> 8))
 
 /* compiled limits of the EM kernel: one epoch / one age bin per thread of a 256-thread workgroup */
 #define COLATE_MAX_EPOCHS 256
@@ -57,6 +68,9 @@ const char* colate_version(void);
 const char* colate_last_error(void);
 int colate_device_count(void);       /* >= 0, or COLATE_ENODEVICE */
 int colate_set_device(int ordinal);  /* device used by the calling thread's later calls */
+/* Diagnostic: which build of the EM kernel a batch of this shape runs on the current device
+ * (0 latency/max-ilp, 1 latency/default scheduler, 2 throughput), or a negative code. */
+int colate_em_kernel_variant(int B, int E);
 
 /* ---- the EM hot path ------------------------------------------------------
  * Replaces coal.cpp:3675-3827 (bootstrap EM driver: coal_EM construction,
@@ -181,6 +195,40 @@ int colate_bootstrap_em_batch(int B, int nb, int E, int A, const double* age_gri
                               int min_iter, double rel_tol, double rate_floor, double* out_rates,
                               int* out_iters, double* out_loglik, int* out_flags,
                               double* out_cnt_shared, double* out_cnt_notshared);
+
+/* The host-pointer entry points above keep one device buffer, one pinned staging buffer and one stream per calling
+ * thread between calls (grown on demand); this frees them. */
+int colate_release_workspace(void);
+
+/* ---- one process per GPU: replicate shards + ONE RCCL all-gather over xGMI -----------
+ * The reference runs its replicates one after the other (coal.cpp:3675-3846); they are independent, so rank r of
+ * `nranks` processes runs the contiguous range colate_shard_bounds(B, nranks, r) on ITS current device and a
+ * single ncclAllGather of the packed results (rates, log-likelihood, iterations, flags: (8E + 16) bytes per
+ * replicate) gives every rank all B results in replicate order -- bit-identical to the one-process run.  No other
+ * exchange exists on the path.  Rank 0 obtains the 128-byte id (colate_comm_unique_id) and hands it to the others
+ * by any means (a pipe, a file, MPI, torch.distributed's store); every rank then calls colate_comm_create after
+ * selecting its device (colate_set_device).  RCCL (librccl.so.1) is loaded on first use.  `Colate --ranks N` is
+ * the command-line form (it forks N such processes itself); colate_amd/distributed.py + bench.py are the
+ * torch.distributed form of the same sharding. */
+#define COLATE_COMM_ID_BYTES 128
+int colate_shard_bounds(int B, int nranks, int rank, int* lo, int* hi);
+int colate_comm_unique_id(void* id /* [COLATE_COMM_ID_BYTES] */);
+int colate_comm_create(const void* id, int nranks, int rank, void** comm);
+int colate_comm_destroy(void* comm);
+/* colate_em_batch over the communicator: every rank passes the FULL host arrays (cnt_*[B][A]) and receives the
+ * full outputs; it computes rows [lo, hi) only. */
+int colate_em_batch_allgather(void* comm, int B, int E, int A, const double* age_grid, const double* cnt_shared,
+                              const double* cnt_notshared, const double* epochs, const double* init_rates,
+                              int max_iter, int min_iter, double rel_tol, double rate_floor, double* out_rates,
+                              int* out_iters, double* out_loglik, int* out_flags);
+/* colate_bootstrap_em_batch over the communicator (weights[B][nb] in full on every rank: they come from the
+ * run's one std::mt19937 stream, which every rank replays identically from --seed). */
+int colate_bootstrap_em_batch_allgather(void* comm, int B, int nb, int E, int A, const double* age_grid, double age,
+                                        const double* weights, const double* sh_block, const double* ns_block,
+                                        const double* sh_emp_block, const double* ns_emp_block, const double* epochs,
+                                        const double* init_rates, int max_iter, int min_iter, double rel_tol,
+                                        double rate_floor, double* out_rates, int* out_iters, double* out_loglik,
+                                        int* out_flags);
 
 /* coal.cpp:3660-3672, 3830-3847: the .coal text (6 significant digits, trailing blank). */
 int colate_write_coal(const char* path, int B, int E, const double* epochs, const double* rates,

@@ -17,12 +17,38 @@
 
 static int absent(double x) { return isinf(x) || isnan(x); }
 
+/* ---- libm-noise hook (checker-side experiment, OFF by default) ----------------------------------------
+ * With a non-zero seed every exp / log / log1p result inside the EM path below is moved to a neighbouring
+ * double at random (1/4 up, 1/4 down, 1/2 unchanged): the result the same source would give when linked
+ * against another libm whose functions are, like glibc's, accurate to < 1 ulp but not correctly rounded
+ * (the reference's own shipped binaries are macOS builds).  tests/oracle_lib.stable_mask uses it to find the
+ * epochs whose value is pinned by the reference's SOURCE rather than by the last bit of one libm.  With the
+ * seed at 0 (the default) the three wrappers are the plain libm calls and the oracle is bit-equal to the
+ * reference build in oracle/_ref (tests/test_oracle_golden.py). */
+static unsigned long long g_libm_noise = 0;
+void oracle_set_libm_noise(unsigned long long seed) { g_libm_noise = seed; }
+static double jitter(double y) {
+  if (!g_libm_noise || !isfinite(y) || y == 0.0) return y;
+  g_libm_noise ^= g_libm_noise << 13;
+  g_libm_noise ^= g_libm_noise >> 7;
+  g_libm_noise ^= g_libm_noise << 17;
+  if (!g_libm_noise) g_libm_noise = 0x9e3779b97f4a7c15ull;
+  switch ((g_libm_noise >> 33) & 3) {
+    case 0: return nextafter(y, INFINITY);
+    case 1: return nextafter(y, -INFINITY);
+    default: return y;
+  }
+}
+static double o_exp(double x) { return jitter(exp(x)); }
+static double o_log(double x) { return jitter(log(x)); }
+static double o_log1p(double x) { return jitter(log1p(x)); }
+
 /* include/coal/coal_EM.cpp:5-31 */
 double oracle_logsumexp(double loga, double logb) {
   if (absent(loga)) return absent(logb) ? LOG0 : logb;
   if (absent(logb)) return loga;
-  if (loga > logb) return loga + log1p(exp(logb - loga));
-  return logb + log1p(exp(loga - logb));
+  if (loga > logb) return loga + o_log1p(o_exp(logb - loga));
+  return logb + o_log1p(o_exp(loga - logb));
 }
 
 /* include/coal/coal_EM.cpp:33-58 */
@@ -30,7 +56,7 @@ double oracle_logminusexp(double loga, double logb) {
   if (absent(loga)) return LOG0;
   if (absent(logb)) return loga;
   if (loga < logb) return LOG0;
-  return loga + log1p(-exp(logb - loga));
+  return loga + o_log1p(-o_exp(logb - loga));
 }
 
 /* include/coal/coal_EM.cpp:97-151 with t_int = epochs, ep_index[i] = i
@@ -45,8 +71,8 @@ void oracle_get_AB(int E, const double* epochs, const double* rates, double* A_e
     double inv = 1.0 / rates[i];
     if (rate > 0 && t_end != 0 && t_end - t_begin > 0) {
       A_ep[i] = oracle_logminusexp(-cs[i], -cs[i + 1]);
-      double b = (t_begin + inv) - (t_end + inv) * exp(-cs[i + 1] + cs[i]);
-      B_ep[i] = log(b) - cs[i];
+      double b = (t_begin + inv) - (t_end + inv) * o_exp(-cs[i + 1] + cs[i]);
+      B_ep[i] = o_log(b) - cs[i];
     } else {
       A_ep[i] = LOG0;
       B_ep[i] = LOG0;
@@ -57,7 +83,7 @@ void oracle_get_AB(int E, const double* epochs, const double* rates, double* A_e
     double rate = rates[i];
     if (rate > 0) {
       A_ep[i] = -cs[i];
-      B_ep[i] = log(epochs[i] + 1.0 / rate) - cs[i];
+      B_ep[i] = o_log(epochs[i] + 1.0 / rate) - cs[i];
     } else {
       A_ep[i] = LOG0;
       B_ep[i] = LOG0;
@@ -117,8 +143,8 @@ double oracle_em_shared(int E, const double* epochs, const double* rates, const 
       double inv = 1.0 / rates[k];
       if (rates[k] > 0) {
         num[e] = oracle_logminusexp(-g.ck, -g.ck1);
-        denom[e] = log((t_begin + inv) / inv - (t_end + inv) / inv * exp(-g.ck1 + g.ck)) +
-                   log(inv) - g.ck;
+        denom[e] = o_log((t_begin + inv) / inv - (t_end + inv) / inv * o_exp(-g.ck1 + g.ck)) +
+                   o_log(inv) - g.ck;
       } else {
         num[e] = LOG0;
         denom[e] = LOG0;
@@ -136,12 +162,12 @@ double oracle_em_shared(int E, const double* epochs, const double* rates, const 
     for (e = 0; e < lim; e++) {
       num[e] -= nc;
       denom[e] -= nc;
-      num[e] = exp(num[e]);
+      num[e] = o_exp(num[e]);
       if (integ > 0.0)
         integ -= num[e];
       else
         integ = 0.0;
-      denom[e] = exp(denom[e]);
+      denom[e] = o_exp(denom[e]);
       denom[e] += -epochs[e] * num[e] + (epochs[e + 1] - epochs[e]) * integ;
       if (denom[e] < 0.0) denom[e] = 0.0;
     }
@@ -149,8 +175,8 @@ double oracle_em_shared(int E, const double* epochs, const double* rates, const 
       e = E - 1;
       num[e] -= nc;
       denom[e] -= nc;
-      num[e] = exp(num[e]);
-      denom[e] = exp(denom[e]);
+      num[e] = o_exp(num[e]);
+      denom[e] = o_exp(denom[e]);
       denom[e] -= epochs[e] * num[e];
       if (denom[e] < 0.0) denom[e] = 0.0;
     }
@@ -173,7 +199,7 @@ double oracle_em_notshared(int E, const double* epochs, const double* rates, con
     double t_begin = age, t_end = epochs[k + 1];
     if (rate > 0) {
       num[k] = oracle_logminusexp(-g.ck2, -g.ck3);
-      denom[k] = log((t_begin + inv) - (t_end + inv) * exp(-g.ck3 + g.ck2)) - g.ck2;
+      denom[k] = o_log((t_begin + inv) - (t_end + inv) * o_exp(-g.ck3 + g.ck2)) - g.ck2;
       nc = num[k];
     } else {
       num[k] = LOG0;
@@ -187,7 +213,7 @@ double oracle_em_notshared(int E, const double* epochs, const double* rates, con
     }
   } else { /* :350-357 (the reference asserts rate > 0 here) */
     num[k] = -g.ck2;
-    denom[k] = log(age + inv) - g.ck2;
+    denom[k] = o_log(age + inv) - g.ck2;
     nc = num[k];
   }
   if (!isinf(nc) && !isnan(nc)) { /* :435-460 */
@@ -200,20 +226,20 @@ double oracle_em_notshared(int E, const double* epochs, const double* rates, con
     for (; e < E - 1; e++) {
       num[e] -= nc;
       denom[e] -= nc;
-      num[e] = exp(num[e]);
+      num[e] = o_exp(num[e]);
       if (integ > 0.0)
         integ -= num[e];
       else
         integ = 0.0;
-      denom[e] = exp(denom[e]);
+      denom[e] = o_exp(denom[e]);
       denom[e] += -epochs[e] * num[e] + (epochs[e + 1] - epochs[e]) * integ;
       if (denom[e] < 0.0) denom[e] = 0.0;
     }
     e = E - 1;
     num[e] -= nc;
     denom[e] -= nc;
-    num[e] = exp(num[e]);
-    denom[e] = exp(denom[e]);
+    num[e] = o_exp(num[e]);
+    denom[e] = o_exp(denom[e]);
     denom[e] -= epochs[e] * num[e];
     if (denom[e] < 0.0) denom[e] = 0.0;
   } else { /* :461-465 */

@@ -103,6 +103,10 @@ double oracle_uniform_real01(oracle_mt19937* g);
 /* coal.cpp:3350-3357: weights[nb]; B==1 -> all ones, else multinomial */
 void oracle_block_weights(oracle_mt19937* g, int nb, int num_bootstrap, double* weights);
 
+/* Checker-side experiment, OFF (seed 0) by default: with a non-zero seed every exp/log/log1p result of the EM
+ * path moves to a neighbouring double at random -- "the same source on another < 1 ulp libm".  Not thread-safe. */
+void oracle_set_libm_noise(unsigned long long seed);
+
 #ifdef __cplusplus
 }
 #endif

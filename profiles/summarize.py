@@ -35,7 +35,45 @@ def main(src, dst):
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     open(dst, "w").write("\n".join(out) + "\n")
     print("\n".join(out))
+    return out
+
+
+def pmc_entry(src, fetch_factor, note):
+    """One entry of profiles/pmc.json (what bench.py puts into `roofline.traffic` / `roofline.latency.pmc`) from a
+    profile directory that has the three PMC passes.  fetch_factor = bytes per FETCH_SIZE-KB/1024 measured by
+    csrc/tools/fetch_calib.hip for the kernel's 8-B-per-lane reads."""
+    import json
+
+    bench = json.load(open(os.path.join(src, "bench.json")))
+    c = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(src, "pmc*", "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "em_kernel" in r["Kernel_Name"]:
+                c[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    m = {k: sum(v) / len(v) for k, v in c.items()}
+    cfg = bench["config"]
+    iters = cfg["em_iterations_mean"] + 1
+    waves = m["SQ_WAVES"]
+    return {
+        "workload": {"replicates": cfg["replicates_rank0"], "epochs": cfg["epochs"], "age_bins": cfg["age_bins"]},
+        "kernel": bench["roofline"]["kernel"], "source": note,
+        "hbm_bytes_per_launch": m["FETCH_SIZE"] * 1024 * fetch_factor + m["WRITE_SIZE"] * 1024,
+        "fetch_size_kb": m["FETCH_SIZE"], "write_size_kb": m["WRITE_SIZE"], "fetch_factor_8B_per_lane": fetch_factor,
+        "valu_active_frac_of_wave_cycles": m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"],
+        "wait_any_frac_of_wave_cycles": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
+        "wait_inst_any_frac_of_wave_cycles": m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"],
+        "waves_per_launch": waves,
+        "valu_insts_per_wave_per_em_iteration": m["SQ_INSTS_VALU"] / waves / iters,
+        "salu_insts_per_wave_per_em_iteration": m["SQ_INSTS_SALU"] / waves / iters,
+        "lds_insts_per_wave_per_em_iteration": m["SQ_INSTS_LDS"] / waves / iters,
+        "units": "SQ_* cycle counters are quad-cycles (guide: s_memtime tick vs SQ PMC units); fractions are ratios of like units",
+    }
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    if sys.argv[1] == "--pmc-entry":  # summarize.py --pmc-entry SRC FETCH_FACTOR NOTE  -> JSON on stdout
+        import json
+
+        print(json.dumps(pmc_entry(sys.argv[2], float(sys.argv[3]), sys.argv[4]), indent=1))
+    else:
+        main(sys.argv[1], sys.argv[2])

@@ -13,6 +13,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Tests marked `gpu` need a HIP device: skip them (visibly) where there is none instead of failing."""
+    if not any("gpu" in item.keywords for item in items):
+        return
+    try:
+        import colate_amd
+
+        have = colate_amd.device_count() >= 1
+    except Exception:  # noqa: BLE001  (no library / no driver: same answer)
+        have = False
+    if have:
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this environment (run with -m gpu on the MI355X box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 def _ensure_built():
     """The C-ABI library and the oracle are built in-tree; build them if a checkout is fresh."""
     lib = os.path.join(ROOT, "colate_amd", "lib", "libcolate_amd.so")

@@ -61,16 +61,21 @@ def test_l2_golden_coal_text_and_iterations(ca, name):
     grid = ol.age_grid()
     ep, _ = ol.epochs_from_bins(c["bins"])
     rates, iters, ll, flags = ca.em_batch(grid, c["csh"], c["cns"], ep)
-    assert (flags == 0).all()
+    assert (ca.status_flags(flags) == 0).all()
     assert iters.tolist() == c["iterations"]
     ref_rows = [np.array(line.split()[2:], dtype=np.float64) for line in c["coal"].split("\n")[2:] if line]
     mine_rows = [np.array(("".join("%g " % x for x in r)).split(), dtype=np.float64) for r in rates]
     r0, _, _, _ = ol.em_batch(grid, c["csh"], c["cns"], ep)
     mask = ol.stable_mask(grid, c["csh"], c["cns"], ep, r0)
-    assert mask.mean() > 0.85
+    unres, unstable = ol.check_rates(rates, flags, r0, mask, RATE_RTOL)
+    if ep.size < 64:  # --bins 3,7,0.2: every epoch is pinned, nothing is flagged, the whole text is identical
+        assert mask.all() and (flags == 0).all()
+    else:  # 122 epochs: the reference's last 16-17 are rounding residue; the kernel says so itself
+        assert (unstable <= 18).all() and (unres >= unstable).all() and (unres <= unstable + 3).all(), (unres, unstable)
     for b in range(len(ref_rows)):
+        keep = ep.size - int(unres[b])  # ... and every token the kernel does not flag is the reference's token
+        assert np.array_equal(mine_rows[b][:keep], ref_rows[b][:keep])
         assert np.array_equal(mine_rows[b][mask[b]], ref_rows[b][mask[b]])
-        assert _rel(rates[b], r0[b])[mask[b]].max() < RATE_RTOL
 
 
 @pytest.mark.parametrize("name", gl.l3_names())
@@ -98,17 +103,9 @@ def test_l3_cli_drop_in(ca, name, tmp_path):
     r0, _, _, _ = ol.em_batch(grid, csh, cns, ep)
     mask = ol.stable_mask(grid, csh, cns, ep, r0)
     first = ep_null if age > 0 else 0  # ancient samples print epochs from ep_null on (coal.cpp:3837)
-    n_same = n_all = 0
-    for b in range(B):
-        m_tok, r_tok = mine[2 + b].split(), ref[2 + b].split()
-        assert m_tok[:2] == r_tok[:2] and len(m_tok) == len(r_tok)
-        for j, e in enumerate(range(first, ep.size)):
-            n_all += 1
-            if m_tok[2 + j] == r_tok[2 + j]:
-                n_same += 1
-            else:
-                assert not mask[b, e], (b, e, m_tok[2 + j], r_tok[2 + j])
-    assert n_same >= 0.9 * n_all
+    assert mask[:, first:].all()  # 23-epoch grids: the checker finds every printed epoch pinned ...
+    for b in range(B):  # ... and the two texts are identical token for token
+        assert mine[2 + b] == ref[2 + b], (b, mine[2 + b], ref[2 + b])
 
 
 def test_edge_cases(ca):
@@ -226,8 +223,9 @@ def test_sharded_entry_point_matches_single_launch(ca):
 
 
 def test_throughput_variant_is_bit_identical(ca, monkeypatch):
-    """The kernel has a latency variant (a wave per role and bin group; B up to twice the CU count) and a
-    throughput variant (two waves per replicate walking through the bin groups; larger B).  Same phases, same
+    """The kernel has a latency variant (a wave per role and bin group; B up to twice the CU count; built twice:
+    max-ilp scheduling for B <= #CUs, default scheduling = one more resident wave per SIMD beyond) and a
+    throughput variant (two waves per replicate walking through the bin groups; larger B, or more than 128 epochs).  Same phases, same
     arithmetic: rates, log-likelihoods, iteration counts and flags agree bit for bit, so results do not depend
     on the batch size a replicate happens to be run in."""
     from colate_amd import workloads
@@ -239,11 +237,13 @@ def test_throughput_variant_is_bit_identical(ca, monkeypatch):
         csh[0, :] = 0.0          # a replicate without shared counts
         cns[1, 60:] = 0.0        # one whose data stop early (one bin group)
         out = {}
-        for variant in ("latency", "throughput"):
+        for variant in ("latency-ilp", "latency", "throughput"):  # (the two latency builds differ in scheduling only)
             monkeypatch.setenv("COLATE_EM_VARIANT", variant)
+            assert ca.em_kernel_variant(nrep, ep.size) == variant
             out[variant] = ca.em_batch(grid, csh, cns, ep)
-        for a, b in zip(out["latency"], out["throughput"]):
-            assert np.array_equal(a, b)
+        for other in ("latency", "throughput"):
+            for a, b in zip(out["latency-ilp"], out[other]):
+                assert np.array_equal(a, b)
     monkeypatch.delenv("COLATE_EM_VARIANT")
     # the library picks the throughput variant by itself for a batch beyond 2 x #CUs: spot-check against the oracle
     ep, _ = ol.epochs_from_bins("3,7,0.2")
@@ -317,7 +317,7 @@ def test_custom_age_grids(ca, A):
     r, it, ll, fl = ca.em_batch(grid, csh, cns, ep, max_iter=1300)
     r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep, max_iter=1300)
     ok = (fl0 & 3) == 0  # (the cap of 1300 iterations may be hit: then both stop there, flagged alike)
-    assert ok.any() and (fl[ok] == fl0[ok]).all()
+    assert ok.any() and (ca.status_flags(fl)[ok] == fl0[ok]).all()
     assert (it[ok] == it0[ok]).all() and np.allclose(ll[ok], ll0[ok], rtol=1e-11, atol=1e-13)
     m = ol.stable_mask(grid, csh, cns, ep, r0, max_iter=1300)
     assert _rel(r, r0)[m & ok[:, None]].max() < RATE_RTOL
@@ -331,7 +331,7 @@ def test_flags(ca):
     csh, cns = workloads.bootstrap_tables(grid, 2, nb=9, scale=1.0)
     # iteration cap reached before the stop rule can fire
     r, it, ll, fl = ca.em_batch(grid, csh, cns, ep, max_iter=50)
-    assert (it == 50).all() and (fl == ca.FLAG_MAXITER).all()
+    assert (it == 50).all() and (ca.status_flags(fl) == ca.FLAG_MAXITER).all()
     r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep, max_iter=50)
     assert _rel(r, r0).max() < 1e-9 and np.allclose(ll, ll0, rtol=1e-12)
     # a not-shared count inside the last epoch with a zero last rate: the reference asserts (coal_EM.cpp:351)

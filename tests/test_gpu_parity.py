@@ -83,11 +83,12 @@ def test_em_matches_oracle_wholegenome_like(ca):
     csh, cns = workloads.bootstrap_tables(grid, 6)
     r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep)
     r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep)
-    assert (fl0 == 0).all() and (fl1 == 0).all()
+    assert (fl0 == 0).all() and (fl1 == 0).all()  # flags 0: clean AND no epoch below the reference's resolution
     assert (it0 == it1).all()
     assert np.allclose(ll1, ll0, rtol=1e-12, atol=0)
     assert _rel(r1, r0).max() < RATE_RTOL
     assert _rel(r1, r0).max() < 1e-9  # what we actually get
+    assert ol.stable_mask(grid, csh, cns, ep, r0).all()  # the checker agrees: all 23 epochs are pinned
 
 
 def test_em_matches_oracle_122_epochs(ca):
@@ -98,11 +99,13 @@ def test_em_matches_oracle_122_epochs(ca):
     csh, cns = workloads.bootstrap_tables(grid, 3, nb=9, scale=1.0)
     r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep)
     r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep)
-    assert (it0 == it1).all()
+    assert (it0 == it1).all() and (ca.status_flags(fl1) == 0).all()
     assert np.allclose(ll1, ll0, rtol=1e-12, atol=0)
     mask = ol.stable_mask(grid, csh, cns, ep, r0)
-    assert mask.mean() > 0.85  # only the far tail is undetermined in the reference
-    assert _rel(r1, r0)[mask].max() < RATE_RTOL
+    unres, unstable = ol.check_rates(r1, fl1, r0, mask, RATE_RTOL)
+    # only the far tail is undetermined in the reference: 104+ of 122 epochs are pinned (measured: 105-106), and the
+    # kernel flags that tail itself -- never fewer epochs than the checker finds unstable, at most 3 more
+    assert (unstable <= 18).all() and (unres >= unstable).all() and (unres <= unstable + 3).all(), (unres, unstable)
 
 
 @pytest.mark.parametrize("bins,E_expect", [("3,7,0.3", 17), ("3,7,0.1", 43), ("3,7,0.07", 61), ("2,7.95,0.03", 202),
@@ -120,7 +123,7 @@ def test_every_kernel_instantiation(ca, bins, E_expect):
     kw = dict(max_iter=60, min_iter=20)
     r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep, **kw)
     r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep, **kw)
-    assert (it0 == it1).all() and ((fl0 & 3) == 0).all() and (fl0 == fl1).all()
+    assert (it0 == it1).all() and ((fl0 & 3) == 0).all() and (fl0 == ca.status_flags(fl1)).all()
     assert np.allclose(ll1, ll0, rtol=1e-12, atol=0)
     mask = ol.stable_mask(grid, csh, cns, ep, r0, **kw)
     assert mask.mean() > 0.8
@@ -150,12 +153,12 @@ def test_sparse_tables_and_the_integ_residue(ca):
     csh, cns = csh[idx], cns[idx]
     r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep)
     r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep)
-    assert ((fl0 & 3) == 0).all() and (fl1 == fl0).all()
+    assert ((fl0 & 3) == 0).all() and (ca.status_flags(fl1) == fl0).all()
     assert (it0 == it1).all() and it0.max() > 1001
     assert np.allclose(ll1, ll0, rtol=1e-11, atol=0)
     mask = ol.stable_mask(grid, csh, cns, ep, r0)
     assert mask.mean() > 0.9
-    assert _rel(r1, r0)[mask].max() < RATE_RTOL
+    ol.check_rates(r1, fl1, r0, mask, RATE_RTOL)
     # the regime is really there: resolved epochs at the floor right behind a rate above 1e-3, in several replicates
     floor_behind_spike = [(r0[b, 1:] == 5e-9) & mask[b, 1:] & (np.maximum.accumulate(r0[b, :-1]) > 1e-3) for b in range(len(idx))]
     assert sum(f.any() for f in floor_behind_spike) >= 3

@@ -1,12 +1,20 @@
 #!/usr/bin/env python3
-"""One-off confidence sweep (GPU box): many bootstrap replicates through the GPU path and through the oracle
-(tests/oracle_lib: the C restatement, in worker processes); reports iteration-count mismatches and the largest
-relative rate difference over the epochs whose oracle value is stable (oracle_lib.stable_mask).
+"""Parity evidence sweep (GPU box): many bootstrap replicates through the GPU path (C ABI) and through the oracle
+(tests/oracle_lib: the C restatement, in worker processes).  Per configuration it records
 
-    python tools/parity_sweep.py [replicates] [scale] [bins] [sample_age_in_years] [Ne2 of the dense tables]
+  * iteration-count mismatches, log-likelihood agreement;
+  * the checker's verdict per epoch (oracle_lib.stable_mask: is the ORACLE's rate reproducible to 1e-8 when its
+    libm rounds differently / its counts move by one ulp?) and the kernel's own (COLATE_UNRESOLVED_EPOCHS);
+  * the largest GPU-vs-oracle relative rate difference over the checker-stable epochs and over the epochs the
+    kernel does not flag;
+  * for the epochs outside the claim: oracle value, GPU value and how far the oracle itself moves in its reruns.
+
+    python tools/parity_sweep.py OUT.json [replicates] [scale] [bins] [sample_age_in_years] [Ne2 of the dense tables]
 (scale <= 0: sparse low-coverage-like tables; a sample age > 0 builds the epochs as for an ancient sample and
-removes the counts of the age bins younger than it)
+removes the counts of the age bins younger than it).  tools/parity_all.sh runs the configurations committed
+under profiles/parity/.
 """
+import json
 import os
 import sys
 import time
@@ -23,8 +31,10 @@ def work(args):
     import oracle_lib as ol
     grid, csh, cns, ep = args
     r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep)
-    mask = ol.stable_mask(grid, csh, cns, ep, r0)
-    return r0, it0, ll0, fl0, mask
+    noise, scaled = ol.rerun_rates(grid, csh, cns, ep)
+    mask = ol.mask_from_reruns(r0, noise + scaled)
+    spread = np.max([np.abs(r - r0) for r in noise], axis=0) / np.maximum(np.abs(r0), 1e-300)
+    return r0, it0, ll0, fl0, mask, spread
 
 
 def main():
@@ -32,14 +42,16 @@ def main():
     from colate_amd import workloads
     import oracle_lib as ol
 
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-    scale = float(sys.argv[2]) if len(sys.argv) > 2 else 11.0
-    bins = sys.argv[3] if len(sys.argv) > 3 else "3,7,0.2"
+    out_path = sys.argv[1]
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+    scale = float(sys.argv[3]) if len(sys.argv) > 3 else 11.0
+    bins = sys.argv[4] if len(sys.argv) > 4 else "3,7,0.2"
     grid = ol.age_grid()
-    age = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+    age = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0
     ep, _ = ol.epochs_from_bins(bins, age, 28.0)
+    E = ep.size
+    ne2 = float(sys.argv[6]) if len(sys.argv) > 6 else 12000.0
     if scale > 0:
-        ne2 = float(sys.argv[5]) if len(sys.argv) > 5 else 12000.0
         csh, cns = workloads.bootstrap_tables(grid, B, nb=115 if scale > 2 else 9, scale=scale, ne2=ne2, seed=int(scale * 100) + B)
     else:  # scale <= 0: sparse, noisy tables (few mutations per bin): slow, irregular convergence
         csh, cns = workloads.sparse_tables(grid, B)
@@ -48,27 +60,62 @@ def main():
         cns[:, grid < age / 28.0] = 0.0
     t = time.time()
     r1, it1, ll1, fl1 = colate_amd.em_batch(grid, csh, cns, ep)
-    print(f"GPU: {B} replicates in {time.time() - t:.3f} s (incl. transfers), flags nonzero: {(fl1 != 0).sum()}", flush=True)
-    chunks = [(grid, csh[i:i + 8], cns[i:i + 8], ep) for i in range(0, B, 8)]
+    gpu_s = time.time() - t
+    unres = colate_amd.unresolved_epochs(fl1)
+    status = colate_amd.status_flags(fl1)
+    print(f"GPU: {B} replicates in {gpu_s:.3f} s (incl. transfers), status flags nonzero: {(status != 0).sum()}", flush=True)
+    chunks = [(grid, csh[i:i + 4], cns[i:i + 4], ep) for i in range(0, B, 4)]
     t = time.time()
     with ProcessPoolExecutor(max_workers=14) as ex:
-        res = list(ex.map(work, chunks))
-    print(f"oracle: {time.time() - t:.1f} s on 14 processes", flush=True)
-    r0 = np.concatenate([x[0] for x in res]); it0 = np.concatenate([x[1] for x in res])
-    ll0 = np.concatenate([x[2] for x in res]); fl0 = np.concatenate([x[3] for x in res]); mask = np.concatenate([x[4] for x in res])
-    ok = (fl0 & 3) == 0
+        res = []
+        for k, x in enumerate(ex.map(work, chunks)):
+            res.append(x)
+            if k % 16 == 0:
+                print(f"  oracle chunk {k}/{len(chunks)} {time.time() - t:.0f} s", flush=True)
+    ora_s = time.time() - t
+    r0, it0, ll0, fl0, mask, spread = (np.concatenate([x[i] for x in res]) for i in range(6))
+    ok = (fl0 & 3) == 0  # replicates the reference itself runs through (no assert)
     rel = np.abs(r1 - r0) / np.maximum(np.abs(r0), 1e-300)
-    print(f"replicates the reference would abort on: {(~ok).sum()}")
-    print(f"iteration counts: {(it1[ok] != it0[ok]).sum()} mismatches of {ok.sum()} (range {it0.min()}..{it0.max()})")
-    print(f"log-likelihood max rel diff: {np.abs(ll1[ok] / ll0[ok] - 1).max():.2e}")
-    print(f"stable epochs: {mask[ok].mean() * 100:.1f} %; max rel rate diff there: {rel[ok][mask[ok]].max():.2e}")
-    bad = np.argwhere((rel > 1e-6) & mask & ok[:, None])
-    print(f"entries beyond 1e-6 among stable epochs: {len(bad)}")
-    for b, e in bad[:8]:
-        lo, hi = max(0, e - 2), min(ep.size, e + 3)
-        print(f"  replicate {b} epoch {e}/{ep.size} iters {it0[b]}: oracle {r0[b, lo:hi]} gpu {r1[b, lo:hi]}")
-        nz = np.nonzero((csh[b] > 0) | (cns[b] > 0))[0]
-        print(f"     data in bins {nz.min()}..{nz.max()} (ages {grid[nz.min()]:.1f}..{grid[nz.max()]:.1f}), epoch starts {ep[lo:hi]}")
+    keep = np.arange(E)[None, :] < (E - unres)[:, None]  # epochs the kernel does not flag
+    unstable = E - mask.sum(axis=1)
+    okm = ok[:, None]
+    rec = {
+        "config": {"replicates": B, "scale": scale, "bins": bins, "epochs": int(E), "sample_age_years": age, "ne2": ne2,
+                   "tables": "bootstrap_tables" if scale > 0 else "sparse_tables"},
+        "gpu_seconds_incl_transfers": gpu_s, "oracle_seconds_14_processes": ora_s,
+        "replicates_reference_aborts_on": int((~ok).sum()),
+        "iterations": {"mismatches": int((it1[ok] != it0[ok]).sum()), "min": int(it0.min()), "max": int(it0.max())},
+        "loglik_max_rel_diff": float(np.abs(ll1[ok] / ll0[ok] - 1).max()),
+        "gpu_status_flags_nonzero": int((status[ok] != 0).sum()),
+        "checker": {"stable_fraction": float(mask[ok].mean()), "unstable_epochs_per_replicate_min_max": [int(unstable[ok].min()), int(unstable[ok].max())],
+                    "max_rel_diff_on_stable": float(rel[mask & okm].max(initial=0.0)),
+                    "entries_beyond_1e-6_on_stable": int(((rel > 1e-6) & mask & okm).sum())},
+        "kernel": {"resolved_fraction": float(keep[ok].mean()), "unresolved_epochs_per_replicate_min_max": [int(unres[ok].min()), int(unres[ok].max())],
+                   "max_rel_diff_on_resolved": float(rel[keep & okm].max(initial=0.0)),
+                   "entries_beyond_1e-6_on_resolved": int(((rel > 1e-6) & keep & okm).sum()),
+                   "replicates_flagging_fewer_epochs_than_checker": int((unres[ok] < unstable[ok]).sum()),
+                   "max_extra_epochs_flagged_vs_checker": int((unres[ok] - unstable[ok]).max())},
+    }
+    # what both sides print on the epochs outside the claim (first three replicates that have any)
+    outside = []
+    for b in np.nonzero(ok & ((unres > 0) | (unstable > 0)))[0][:3]:
+        first = int(min(E - unres[b], E - unstable[b]))
+        outside.append({"replicate": int(b), "iterations": int(it0[b]), "first_epoch_outside": first,
+                        "epoch": list(range(first, E)),
+                        "oracle_rate": [float(x) for x in r0[b, first:]], "gpu_rate": [float(x) for x in r1[b, first:]],
+                        "oracle_text": ["%g" % x for x in r0[b, first:]], "gpu_text": ["%g" % x for x in r1[b, first:]],
+                        "gpu_vs_oracle_rel": [float(x) for x in rel[b, first:]],
+                        "oracle_own_spread_under_libm_noise": [float(x) for x in spread[b, first:]],
+                        "checker_stable": [bool(x) for x in mask[b, first:]], "kernel_resolved": [bool(x) for x in keep[b, first:]]})
+    rec["outside_the_claim_examples"] = outside
+    bad = np.argwhere((rel > 1e-6) & (mask | keep) & okm)
+    rec["violations"] = [{"replicate": int(b), "epoch": int(e), "oracle": float(r0[b, e]), "gpu": float(r1[b, e]),
+                          "checker_stable": bool(mask[b, e]), "kernel_resolved": bool(keep[b, e]), "iterations": int(it0[b])}
+                         for b, e in bad[:16]]
+    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+    json.dump(rec, open(out_path, "w"), indent=1)
+    brief = {k: rec[k] for k in ("config", "iterations", "checker", "kernel")}
+    print(json.dumps(brief), flush=True)
 
 
 if __name__ == "__main__":
