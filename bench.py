@@ -106,7 +106,11 @@ def cpu_baseline(grid, csh, cns, epochs, gpu_rates, gpu_iters, bins=BINS):
             dt = time.perf_counter() - t0
             if r.returncode == 0 and os.path.exists(os.path.join(d, "OUT.coal")):
                 lines = open(os.path.join(d, "OUT.coal")).read().split("\n")
-                ref_iters = [int(l.rsplit(" ", 1)[1]) for l in r.stderr.split("\n") if l.startswith("Bootstrap ")]
+                last = {}  # the reference rewrites its progress line ("...iterations N\r"): keep the last count per replicate
+                for l in r.stderr.replace("\r", "\n").split("\n"):
+                    if l.startswith("Bootstrap "):
+                        last[int(l.split()[1].rstrip(":"))] = int(l.rsplit(" ", 1)[1])
+                ref_iters = [last.get(b + 1) for b in range(S)]
                 diff_per_epoch = np.zeros(E, dtype=np.int64)
                 for b in range(S):
                     ref_tok = lines[2 + b].split()[2:]
@@ -340,7 +344,10 @@ def run_rank(args):
         except (OSError, KeyError, ValueError):
             pass
         bytes_per_rep_iter = 2 * A * 8 + A * 8 + 3 * E * 8  # 4992 B at E=23
-        variant = "dry-run" if dry else colate_amd.em_kernel_variant(n_local, E)
+        try:
+            variant = "dry-run" if dry else colate_amd.em_kernel_variant(n_local, E)
+        except AttributeError:  # (an older library build under COLATE_AMD_LIB)
+            variant = "n/a"
         nch = 1 if E <= 64 else (2 if E <= 128 else 4)
         rows = (1 if E <= 16 else (2 if E <= 32 else 4)) if nch == 1 else 4
         kernel_name = f"em_kernel<0, {nch}, {rows}, {'true' if variant == 'throughput' else 'false'}>"

@@ -7,7 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcolate_amd.so")
+# COLATE_AMD_LIB=<path>: load another build of the same library (tools/ab_bench.sh compares builds this way
+# instead of copying candidates over the product library)
+LIB_PATH = os.environ.get("COLATE_AMD_LIB") or os.path.join(_HERE, "lib", "libcolate_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -69,7 +71,12 @@ SIGNATURES = {
 }
 
 for _name, (_res, _args) in SIGNATURES.items():
-    _f = getattr(lib, _name)  # AttributeError here = header and library out of sync
+    try:
+        _f = getattr(lib, _name)  # AttributeError here = header and library out of sync
+    except AttributeError:
+        if os.environ.get("COLATE_AMD_LIB"):  # an older build under comparison may lack newer entry points
+            continue
+        raise
     _f.restype = _res
     _f.argtypes = _args
 

@@ -210,8 +210,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   double* s_nd = s_out + 2 * kNumBinArrays * APZ;    // [2 roles][2][EPAD] partial N, D per role
   double* s_cfail = s_nd + 4 * EPAD;                 // [2 roles][APZ] counts of bins whose normaliser failed
   double* s_cnt = s_cfail + 2 * APZ;                 // [2 roles][APZ] counts
-  double* s_ll = s_cnt + 2 * APZ;                    // [8] per-wave log-likelihood partials
-  double* s_age = s_ll + 8;                          // [AP] age grid (throughput variant)
+  double* s_ll = s_cnt + 2 * APZ;                    // [8] per-wave log-likelihood partials + [2] total counts per kind
+  double* s_age = s_ll + 10;                         // [AP] age grid (throughput variant)
   int* s_kb = reinterpret_cast<int*>(s_age + AP);    // [AP + 1] epoch of each bin
   int* s_fail = s_kb + AP + 1;                       // [8] per-wave "a bin failed" flags
   int* s_misc = s_fail + 8;                          // [4] nzlo, nzhi, flags
@@ -355,12 +355,16 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   // epochs.  The factored sums below are exact there (mass 0), so the residue is put in explicitly: without it
   // those epochs would get the ratio of two vanishing numbers instead of the reference's floor.
   constexpr double kIntegResidue = 4.0e-17;
-  constexpr double kResolvedRatio = 1.0e8;  // epilogue: denominators below this many residues are not reproducible to 1e-8
+  // epilogue: a denominator below this many residues is not reproducible to 1e-8.  Measured on the reference (its rates
+  // under 1-ulp libm noise, tools/parity_sweep.py): relative spread of a rate ~ 100 / (denominator / (dt_e * residue)) --
+  // integ accumulates the rounding of each of the ~100 terms it subtracts -- so 1e-8 needs a ratio of 1e10; x3 margin.
+  constexpr double kResolvedRatio = 3.0e10;
   double c_all = 0.0;
   for (int b = 0; b < A; b++) c_all += s_cnt[role * APZ + b];
   double eta_e[NCH];  // dt_e * residue of this role's bins (0 in the last epoch, which has no dt_e * integ term)
 #pragma unroll
   for (int c = 0; c < NCH; c++) eta_e[c] = dt_e[c] * (kIntegResidue * c_all);
+  if (tid < 2 * kWave && lane == 0) s_ll[8 + role] = c_all;  // both kinds' totals, for the epilogue (no register carries them)
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
     const int e = c * kWave + lane;
@@ -924,16 +928,13 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     // through the coupling of the EM every OLDER epoch moves with it.  Exception: where the denominator is nothing but
     // residue and the rate sits on the floor, the floor is what every build prints.  The count of such trailing epochs
     // goes out in the high bits of out_flags (COLATE_FLAG_UNRESOLVED, COLATE_UNRESOLVED_EPOCHS()).
-    double c_tot = 0.0;
-    for (int b = 0; b < A; b++) c_tot += s_cnt[b] + s_cnt[APZ + b];
     int first_bad = E;
 #pragma unroll
     for (int c = NCH - 1; c >= 0; c--) {
       const int e = c * kWave + lane;
       const double D = s_nd[1 * EPAD + e] + s_nd[3 * EPAD + e];  // denominators of the last E-step
-      const double eta = dt_e[c] * (kIntegResidue * c_tot);
-      const bool resolved = !ep_on[c] || e >= E - 1 || D >= kResolvedRatio * eta ||
-                            (lam_e[c] <= p.rate_floor && D < 3.0 * eta);
+      const double eta = dt_e[c] * (kIntegResidue * (s_ll[8] + s_ll[9]));  // dt_e * residue of ALL bins (both kinds); 0 in the last epoch and beyond E
+      const bool resolved = D >= kResolvedRatio * eta || (lam_e[c] <= p.rate_floor && D < 3.0 * eta);
       const unsigned long long bad = __ballot(!resolved);
       if (bad) first_bad = c * kWave + __builtin_ctzll(bad);
     }
@@ -975,7 +976,7 @@ inline size_t em_lds_bytes(int E, int A) {
   const size_t EPAD = (size_t)em_chunks(E) * kWave;
   const size_t AP = (size_t)em_groups(A) * kWave;
   const size_t APZ = AP + 16;
-  const size_t doubles = (EPAD + 1) + kNumGather * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ + 8 + AP;
+  const size_t doubles = (EPAD + 1) + kNumGather * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ + 10 + AP;
   const size_t ints = (AP + 1) + 8 + 4 + AP;
   return doubles * sizeof(double) + ints * sizeof(int);
 }

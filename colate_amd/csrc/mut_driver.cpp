@@ -786,6 +786,11 @@ int run_mut_pairs(const Options& opt) {
     std::cerr << "Error: --pairs needs --mut and --bins (and optionally --chr, --num_bootstraps, --seed)." << std::endl;
     return 1;
   }
+  for (const char* o : {"target_mask", "reference_mask", "coal"})
+    if (opt.has(o)) {  // per-sample masks / one warm start cannot apply to a whole list of pairs: refuse, do not ignore
+      std::cerr << "Error: --" << o << " cannot be combined with --pairs (run such pairs one by one)." << std::endl;
+      return 1;
+    }
   std::vector<PairSpec> pairs;
   {
     std::ifstream is(opt.get("pairs"));

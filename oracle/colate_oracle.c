@@ -394,6 +394,88 @@ int oracle_epochs_from_bins(const char* bins, double age, double years_per_gen, 
   return E;
 }
 
+/* include/coal/coal.cpp:3508-3549 (epochs from line 2 of a .coal file: blank/tab separated tokens through std::stof,
+ * i.e. FLOAT precision; for an ancient sample `age` takes the place of the second epoch when it is younger than it)
+ * and :3638-3646 (starting rates: skip two numbers, then one `is >> double` per epoch -- extraction simply runs on into
+ * the next line when `age` added an epoch; at end of file the default 1/20000 stays, coal.cpp:3636).
+ * Returns E, or < 0 where the reference asserts (:3540-3546) / cannot read. */
+#include <stdio.h>
+int oracle_epochs_from_coal(const char* path, double age, double* epochs, double* init_rates, int cap) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return -3;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  char* buf = (char*)malloc((size_t)n + 1);
+  if (fread(buf, 1, (size_t)n, f) != (size_t)n) {
+    fclose(f);
+    free(buf);
+    return -3;
+  }
+  fclose(f);
+  buf[n] = 0;
+  char* l2 = strchr(buf, '\n'); /* getline x 2: the second line holds the epochs */
+  if (!l2) {
+    free(buf);
+    return -1;
+  }
+  l2++;
+  char* l2end = strchr(l2, '\n');
+  char* rest = l2end ? l2end + 1 : buf + n;
+  if (l2end) *l2end = 0;
+  int E = 0, ep = 0;
+  char tmp[128];
+  size_t l = 0;
+  for (char* c = l2;; c++) { /* :3514-3539 */
+    int sep = (*c == ' ' || *c == '\t');
+    if (sep || *c == 0) {
+      if (*c == 0 && l == 0) break; /* `if(tmp != "")` */
+      tmp[l] = 0;
+      double v = (double)strtof(tmp, NULL);
+      if (ep == 1 && age < v && age != 0.0) {
+        if (E >= cap) return -2;
+        epochs[E++] = age;
+        ep++;
+      }
+      if (ep != 1 || age == 0.0) {
+        if (E >= cap) return -2;
+        epochs[E++] = v;
+        ep++;
+      }
+      l = 0;
+      if (*c == 0) break;
+    } else if (l + 1 < sizeof(tmp)) {
+      tmp[l++] = *c;
+    }
+  }
+  if ((age != 0.0 && ep <= 2) || (age == 0.0 && ep <= 1) || epochs[0] != 0) { /* :3540-3543 */
+    free(buf);
+    return -1;
+  }
+  for (int e = 1; e < E; e++)
+    if (!(epochs[e] > epochs[e - 1])) { /* :3544-3546 */
+      free(buf);
+      return -1;
+    }
+  for (int e = 0; e < E; e++) init_rates[e] = 1.0 / 20000.0; /* :3636-3637 */
+  char* p = rest;
+  int good = 1;
+  for (int k = -2; k < E && good; k++) { /* :3640-3644, formatted extraction */
+    while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r') p++;
+    if (*p == 0) break; /* end of file while skipping blanks: the value is left alone */
+    char* q;
+    double v = strtod(p, &q);
+    if (q == p) { /* not a number: C++11 stores 0 and the stream fails for good */
+      v = 0.0;
+      good = 0;
+    }
+    p = q;
+    if (k >= 0) init_rates[k] = v;
+  }
+  free(buf);
+  return E;
+}
+
 /* include/coal/coal.cpp:3358-3441 for one replicate; emp tables reduced to their row 0
  * (bin1 loop runs once, coal.cpp:3397). */
 void oracle_bootstrap_counts(int nb, int A, const double* age_grid, double age,

@@ -77,6 +77,9 @@ int oracle_age_grid(double* age_grid, int cap);
 int oracle_epochs_from_bins(const char* bins, double age, double years_per_gen, double* epochs,
                             int cap, int* ep_null);
 
+/* coal.cpp:3508-3549 + 3638-3646: epochs (float-parsed) and starting rates from a `--coal` file. */
+int oracle_epochs_from_coal(const char* path, double age, double* epochs, double* init_rates, int cap);
+
 /* coal.cpp:3350-3451 for one replicate, given the block weights:
  * weighted block sums (3358-3390; only emp row 0 is live) and the F
  * redistribution of emp row 0 into the shared counts (3392-3441).

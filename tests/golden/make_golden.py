@@ -130,21 +130,82 @@ def make_l3():
         "l3_nochr": dict(gen=dict(chroms=("1",), snps_per_chr=1200, seed=3, gz=False, with_chr_file=False),
                          args=["--bins", "3,6,0.5", "--seed", "9", "--num_bootstraps", "1"]),
     }
+    # --coal warm start (coal.cpp:3508-3549, 3638-3646): epochs and starting rates from a Relate-style .coal file with
+    # strictly increasing epochs (the reference asserts that, :3544-3546 -- a .coal written by `--mode mut --bins` itself
+    # starts "0 0 ..." and is refused); modern, and ancient (the sample age replaces the epochs younger than it)
+    rng = np.random.default_rng(99)
+    prev_epochs = np.concatenate([[0.0], 10 ** np.arange(3.0, 7.01, 0.25) / 28.0, [1e8 / 28.0]])
+    prev_rates = np.exp(rng.uniform(np.log(2e-6), np.log(4e-4), (2, prev_epochs.size)))
+    prev_coal = "group\n" + "".join("%g " % x for x in prev_epochs) + "\n" + "".join(
+        "0 %d " % i + "".join("%g " % x for x in r) + "\n" for i, r in enumerate(prev_rates))
+    cases["l3_coal_modern"] = dict(gen=dict(chroms=("1", "2"), snps_per_chr=1000, seed=21, gz=True), extra={"prev.coal": prev_coal},
+                                   args=["--coal", "prev.coal", "--seed", "3", "--num_bootstraps", "2", "--chr", "chr.txt"])
+    cases["l3_coal_ancient"] = dict(inputs_from="l3_coal_modern",
+                                    args=["--coal", "prev.coal", "--seed", "4", "--num_bootstraps", "2", "--chr", "chr.txt",
+                                          "--target_age", "7000"])
+    # --target_mask / --reference_mask (coal.cpp:2169-2174, data.cpp:213-235): per-chromosome fasta files, a site is used
+    # only where both masks say 'P' (case-insensitive: the reader upper-cases); the reference mask of chromosome 2 is
+    # shorter than the chromosome (sites beyond its end are not masked)
+    def mask_text(n, seed, lower=False):
+        r = np.random.default_rng(seed)
+        seq = []
+        while sum(len(x) for x in seq) < n:
+            seq.append(("p" if lower and r.uniform() < 0.3 else "P") * int(r.integers(20_000, 120_000)))
+            seq.append(("N" if r.uniform() < 0.7 else "n") * int(r.integers(5_000, 40_000)))
+        seq = "".join(seq)[:n]
+        return ">mask\n" + "\n".join(seq[i:i + 100] for i in range(0, n, 100)) + "\n"
+    span = 3_000_000
+    cases["l3_masks"] = dict(gen=dict(chroms=("1", "2"), snps_per_chr=1200, seed=31, gz=True, span=span),
+                             extra_gz={"TM_chr1.fa": mask_text(span, 1), "TM_chr2.fa": mask_text(span, 2, lower=True),
+                                       "RM_chr1.fa": mask_text(span, 3, lower=True), "RM_chr2.fa": mask_text(2_000_000, 4)},
+                             args=["--bins", "3,7,0.2", "--seed", "6", "--num_bootstraps", "4", "--chr", "chr.txt",
+                                   "--target_mask", "TM", "--reference_mask", "RM"])
     for name, c in cases.items():
         d = os.path.join(HERE, name)
         shutil.rmtree(d, ignore_errors=True)
-        synth_files.write_inputs(d, **c["gen"])
-        mut_arg = "P" if c["gen"].get("with_chr_file", True) else "P.mut"
-        args = ["--mode", "mut", "--mut", mut_arg, "--target_tmp", "T.colate.in", "--reference_tmp", "R.colate.in"] + c["args"] + ["-o", "expected"]
-        err, iters = run_ref(args, d)
+        with tempfile.TemporaryDirectory() as work:
+            src = os.path.join(HERE, c["inputs_from"]) if "inputs_from" in c else None
+            gen = c.get("gen") or cases[c["inputs_from"]]["gen"]
+            if src:  # same input files as another case: stage that case (its files are stored once)
+                import golden_lib
+                golden_lib.l3_stage(c["inputs_from"], work)
+                os.makedirs(d)
+            else:
+                synth_files.write_inputs(d, **gen)
+                for fn, text in c.get("extra", {}).items():
+                    open(os.path.join(d, fn), "w").write(text)
+                for fn, text in c.get("extra_gz", {}).items():  # the readers fall back to <name>.gz (igzstream)
+                    with gzip.GzipFile(os.path.join(d, fn + ".gz"), "wb", mtime=0) as g:
+                        g.write(text.encode())
+            run_dir = work if src else d
+            mut_arg = "P" if gen.get("with_chr_file", True) else "P.mut"
+            args = ["--mode", "mut", "--mut", mut_arg, "--target_tmp", "T.colate.in", "--reference_tmp", "R.colate.in"] + c["args"] + ["-o", "expected"]
+            err, iters = run_ref(args, run_dir)
+            if src:
+                shutil.copy(os.path.join(work, "expected.coal"), os.path.join(d, "expected.coal"))
         nblocks = int(re.search(r"Number of blocks: (\d+)", err).group(1))
-        json.dump({"generator": "tests/golden/make_golden.py (oracle/_ref/Colate_ref)", "args": args, "iterations": iters,
-                   "num_blocks": nblocks}, open(os.path.join(d, "case.json"), "w"))
+        meta = {"generator": "tests/golden/make_golden.py (oracle/_ref/Colate_ref)", "args": args, "iterations": iters,
+                "num_blocks": nblocks}
+        if src:
+            meta["inputs_from"] = c["inputs_from"]
+        if "--coal" in args:  # the starting rates the reference printed (coal.cpp:3642) pin the --coal reader on their own
+            line = [l for l in err.split("\n") if l.strip() and all(_isnum(t) for t in l.split())]
+            meta["init_rates_printed"] = line[-1].split()
+        json.dump(meta, open(os.path.join(d, "case.json"), "w"))
         for fn in ("T.colate.in", "R.colate.in"):  # keep the fixtures small
-            with open(os.path.join(d, fn), "rb") as f, gzip.GzipFile(os.path.join(d, fn + ".gz"), "wb", mtime=0) as g:
-                g.write(f.read())
-            os.remove(os.path.join(d, fn))
+            if os.path.exists(os.path.join(d, fn)):
+                with open(os.path.join(d, fn), "rb") as f, gzip.GzipFile(os.path.join(d, fn + ".gz"), "wb", mtime=0) as g:
+                    g.write(f.read())
+                os.remove(os.path.join(d, fn))
         print(f"{name}: blocks={nblocks} iterations={iters}")
+
+
+def _isnum(t):
+    try:
+        float(t)
+        return True
+    except ValueError:
+        return False
 
 
 if __name__ == "__main__":

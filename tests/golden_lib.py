@@ -47,6 +47,10 @@ def l3_stage(name, dst):
     """Copy an L3 case into `dst`, decompressing the .colate.in files (the reference freads them raw)."""
     src = os.path.join(HERE, name)
     os.makedirs(dst, exist_ok=True)
+    meta = json.load(open(os.path.join(src, "case.json")))
+    if "inputs_from" in meta:  # this case runs on another case's input files (stored once)
+        l3_stage(meta["inputs_from"], dst)
+        os.remove(os.path.join(dst, "expected.coal"))
     for f in os.listdir(src):
         if f.endswith(".colate.in.gz"):
             with gzip.open(os.path.join(src, f), "rb") as g, open(os.path.join(dst, f[:-3]), "wb") as o:
@@ -78,3 +82,12 @@ def read_counts(path, B, A=185):
     grid = v[:A]
     rest = v[A:].reshape(B, 2, A)
     return grid, rest[:, 0, :].copy(), rest[:, 1, :].copy()
+
+
+def write_colate_mat(path, grid, csh, cns):
+    """The reference's .colate_mat layout (coal.cpp:3481-3497), 17 significant digits as make_golden.py wrote it."""
+    with open(path, "w") as f:
+        f.write(" ".join("%.17g" % x for x in grid) + "\n")
+        for b in range(len(csh)):
+            f.write(" ".join("%.17g" % x for x in csh[b]) + "\n")
+            f.write(" ".join("%.17g" % x for x in cns[b]) + "\n")

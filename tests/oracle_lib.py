@@ -25,6 +25,7 @@ O.oracle_mstep.argtypes = [c_int, dp, dp, c_double, dp]
 O.oracle_em_batch.argtypes = [c_int] * 3 + [dp] * 5 + [c_int, c_int, c_double, c_double, dp, ip, dp, ip]
 O.oracle_age_grid.argtypes = [dp, c_int]
 O.oracle_epochs_from_bins.argtypes = [ctypes.c_char_p, c_double, c_double, dp, c_int, ip]
+O.oracle_epochs_from_coal.argtypes = [ctypes.c_char_p, c_double, dp, dp, c_int]
 O.oracle_bootstrap_counts.argtypes = [c_int, c_int, dp, c_double, dp, dp, dp, dp, dp, dp, dp]
 O.oracle_mt_seed.argtypes = [ctypes.c_void_p, ctypes.c_uint]
 O.oracle_mt_next.restype = ctypes.c_uint
@@ -65,6 +66,13 @@ def epochs_from_bins(bins, age=0.0, ypg=28.0):
     n = O.oracle_epochs_from_bins(bins.encode(), age, ypg, P(ep), 512, ctypes.byref(en))
     assert n > 0
     return ep[:n].copy(), en.value
+
+
+def epochs_from_coal(path, age=0.0):
+    ep, r = np.zeros(512), np.zeros(512)
+    n = O.oracle_epochs_from_coal(str(path).encode(), age, P(ep), P(r), 512)
+    assert n > 0, n
+    return ep[:n].copy(), r[:n].copy()
 
 
 def get_AB(epochs, rates):

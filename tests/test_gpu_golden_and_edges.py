@@ -78,6 +78,39 @@ def test_l2_golden_coal_text_and_iterations(ca, name):
         assert np.array_equal(mine_rows[b][mask[b]], ref_rows[b][mask[b]])
 
 
+@pytest.mark.parametrize("name", gl.l2_names())
+def test_colate_mat_hook_three_way(ca, name, tmp_path):
+    """The reference's hook for precomputed count tables (coal.cpp:3169-3170, 3471-3499): OUR command line loads the
+    same OUT.colate_mat the reference binary was given when the golden was made, so reference .coal, our .coal and the
+    oracle's rates are a three-way comparison on identical counts (23 and 122 epochs)."""
+    c = gl.l2_case(name)
+    B = len(c["iterations"])
+    grid = ol.age_grid()
+    gl.write_colate_mat(tmp_path / "OUT.colate_mat", grid, c["csh"], c["cns"])
+    r = subprocess.run([CLI, "--mode", "mut", "--mut", "dummy", "--bins", c["bins"], "--num_bootstraps", str(B), "-o", "OUT"],
+                       cwd=str(tmp_path), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    err = r.stderr.decode()
+    assert "Loading precomputed file OUT.colate_mat" in err
+    assert [int(l.rsplit(" ", 1)[1]) for l in err.split("\n") if l.startswith("Bootstrap ")] == c["iterations"]
+    mine = (tmp_path / "OUT.coal").read_text().split("\n")
+    ref = c["coal"].split("\n")
+    assert mine[:2] == ref[:2] and len(mine) == len(ref)
+    ep, _ = ol.epochs_from_bins(c["bins"])
+    r0, _, _, _ = ol.em_batch(grid, c["csh"], c["cns"], ep)
+    assert gl.coal_text(ep, r0) == c["coal"]  # oracle == reference, whole text
+    mask = ol.stable_mask(grid, c["csh"], c["cns"], ep, r0)
+    note = [l for l in err.split("\n") if l.startswith("Note: the last ")]
+    k_cli = int(note[0].split()[3]) if note else 0
+    unstable = ep.size - mask.sum(axis=1)
+    assert unstable.max() <= k_cli <= unstable.max() + 3
+    if ep.size < 64:
+        assert k_cli == 0 and mine == ref  # 23 epochs: identical files
+    for b in range(B):
+        m_tok, r_tok = mine[2 + b].split(), ref[2 + b].split()
+        assert m_tok[: 2 + ep.size - k_cli] == r_tok[: 2 + ep.size - k_cli]
+
+
 @pytest.mark.parametrize("name", gl.l3_names())
 def test_l3_cli_drop_in(ca, name, tmp_path):
     """`Colate --mode mut` of colate_amd on the reference's input files and --seed: same stderr
@@ -99,13 +132,29 @@ def test_l3_cli_drop_in(ca, name, tmp_path):
     age = 0.0
     if "--target_age" in args:
         age = float(np.float32(args[args.index("--target_age") + 1])) / 28.0
-    ep, ep_null = ol.epochs_from_bins(args[args.index("--bins") + 1], age, 28.0)
-    r0, _, _, _ = ol.em_batch(grid, csh, cns, ep)
-    mask = ol.stable_mask(grid, csh, cns, ep, r0)
+    kw = {}
+    if "--coal" in args:  # warm start from a .coal file (coal.cpp:3508-3549, 3638-3646)
+        ep, kw["init"] = ol.epochs_from_coal(tmp_path / args[args.index("--coal") + 1], age)
+        ep_null = 0
+    else:
+        ep, ep_null = ol.epochs_from_bins(args[args.index("--bins") + 1], age, 28.0)
+    r0, _, _, _ = ol.em_batch(grid, csh, cns, ep, **kw)
+    mask = ol.stable_mask(grid, csh, cns, ep, r0, **kw)
     first = ep_null if age > 0 else 0  # ancient samples print epochs from ep_null on (coal.cpp:3837)
-    assert mask[:, first:].all()  # 23-epoch grids: the checker finds every printed epoch pinned ...
-    for b in range(B):  # ... and the two texts are identical token for token
-        assert mine[2 + b] == ref[2 + b], (b, mine[2 + b], ref[2 + b])
+    # With these small two-chromosome inputs the second-to-last epoch of some replicates has (almost) no data: the
+    # reference's own rate there moves by ~1 % under libm noise (stable_mask).  Everything the checker finds pinned must
+    # be the reference's token; the CLI's note must cover at least the epochs the checker finds unstable.
+    unstable = ep.size - mask.sum(axis=1)
+    assert mask.mean() > 0.9
+    note = [l for l in err.split("\n") if l.startswith("Note: the last ")]
+    k_cli = int(note[0].split()[3]) if note else 0
+    assert unstable.max() <= k_cli <= unstable.max() + 3, (k_cli, unstable)
+    for b in range(B):
+        m_tok, r_tok = mine[2 + b].split(), ref[2 + b].split()
+        assert m_tok[:2] == r_tok[:2] and len(m_tok) == len(r_tok)
+        for j, e in enumerate(range(first, ep.size)):
+            if m_tok[2 + j] != r_tok[2 + j]:
+                assert not mask[b, e] and e >= ep.size - k_cli, (b, e, m_tok[2 + j], r_tok[2 + j])
 
 
 def test_edge_cases(ca):

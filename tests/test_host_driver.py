@@ -158,10 +158,21 @@ def test_cli_feeder_and_bootstrap_reproduce_reference(name, tmp_path):
     assert np.array_equal(grid, ol.age_grid())
     age = 0.0
     if "--target_age" in args:
-        age = max(float(np.float32(args[args.index("--target_age") + 1])),
-                  float(np.float32(args[args.index("--reference_age") + 1]))) / 28.0
-    ep, ep_null = ol.epochs_from_bins(args[args.index("--bins") + 1], age, 28.0)
-    rates, iters, ll, fl = ol.em_batch(grid, csh, cns, ep)
+        ref_age = args[args.index("--reference_age") + 1] if "--reference_age" in args else "0"
+        age = max(float(np.float32(args[args.index("--target_age") + 1])), float(np.float32(ref_age))) / 28.0
+    init = None
+    if "--coal" in args:  # warm start: epochs (float-parsed) and starting rates from the file (coal.cpp:3508-3549, 3638-3646)
+        prev = tmp_path / args[args.index("--coal") + 1]
+        ep, init = ol.epochs_from_coal(prev, age)
+        ep_null = 0
+        import colate_amd
+
+        ep_p, init_p = colate_amd.epochs_from_coal(prev, age)  # the product's reader against the oracle's restatement ...
+        assert np.array_equal(ep_p, ep) and np.array_equal(init_p, init)
+        assert ["%g" % x for x in init] == case["init_rates_printed"]  # ... and both against what the reference printed
+    else:
+        ep, ep_null = ol.epochs_from_bins(args[args.index("--bins") + 1], age, 28.0)
+    rates, iters, ll, fl = ol.em_batch(grid, csh, cns, ep, init=init)
     assert iters.tolist() == case["iterations"]
     assert gl.coal_text(ep, rates, age > 0, ep_null) == (tmp_path / "expected.coal").read_text()
 
@@ -195,3 +206,54 @@ def test_pairs_mode_counts_equal_separate_runs(tmp_path):
                                "-o", out + "_single", "--counts_out", out + "_single.counts", "--counts_only"], str(tmp_path))
         assert r.returncode == 0, r.stderr.decode()[-800:]
         assert (tmp_path / (out + ".counts")).read_text() == (tmp_path / (out + "_single.counts")).read_text()
+
+
+def test_masks_change_the_tables(tmp_path):
+    """The mask fixture really exercises the mask branch (coal.cpp:2169-2174): without the two masks the same
+    inputs give different count tables."""
+    case = gl.l3_stage("l3_masks", str(tmp_path))
+    args = [a for a in case["args"]]
+    args[args.index("-o") + 1] = "mine"
+    r = _run_cli(args + ["--counts_out", "with.counts", "--counts_only"], str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    nomask = [a for i, a in enumerate(args) if a not in ("--target_mask", "--reference_mask")
+              and (i == 0 or args[i - 1] not in ("--target_mask", "--reference_mask"))]
+    r = _run_cli(nomask + ["--counts_out", "without.counts", "--counts_only"], str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    _, sh1, ns1 = gl.read_counts(tmp_path / "with.counts", 4)
+    _, sh2, ns2 = gl.read_counts(tmp_path / "without.counts", 4)
+    assert (sh1 + ns1).sum() < 0.9 * (sh2 + ns2).sum()  # the masks remove sites
+
+
+def test_coal_file_written_by_bins_run_is_refused_like_the_reference(tmp_path):
+    """A .coal written by `--mode mut --bins` starts "0 0 ...": the reference asserts strictly increasing epochs
+    (coal.cpp:3544-3546) and aborts on it; the library returns an error instead."""
+    import colate_amd
+
+    with pytest.raises(colate_amd.ColateError):
+        colate_amd.epochs_from_coal(os.path.join(gl.HERE, "l3_modern", "expected.coal"))
+
+
+def test_pairs_refuses_masks_and_coal(tmp_path):
+    """--pairs shares one option set over many samples: per-sample masks and a --coal warm start have no meaning
+    there and are refused (instead of being silently ignored)."""
+    case = gl.l3_stage("l3_masks", str(tmp_path))
+    (tmp_path / "pairs.txt").write_text("T.colate.in R.colate.in ab\n")
+    base = ["--mode", "mut", "--mut", "P", "--chr", "chr.txt", "--bins", "3,7,0.2", "--seed", "5", "--pairs", "pairs.txt", "--counts_only"]
+    for extra in (["--target_mask", "TM"], ["--reference_mask", "RM"], ["--coal", "x.coal"]):
+        r = _run_cli(base + extra, str(tmp_path))
+        assert r.returncode != 0 and b"--pairs" in r.stderr, r.stderr.decode()[-300:]
+
+
+@pytest.mark.parametrize("name", ["wg_e23", "wg_e122"])
+def test_colate_mat_loader_round_trip(name, tmp_path):
+    """load_colate_mat (the reference's precomputed-table hook, coal.cpp:3471-3499) without a GPU: the tables our
+    CLI loads from OUT.colate_mat come back bit for bit through --counts_out (both sides 17 significant digits)."""
+    c = gl.l2_case(name)
+    B = len(c["iterations"])
+    gl.write_colate_mat(tmp_path / "OUT.colate_mat", ol.age_grid(), c["csh"], c["cns"])
+    r = _run_cli(["--mode", "mut", "--mut", "dummy", "--bins", c["bins"], "--num_bootstraps", str(B), "-o", "OUT",
+                  "--counts_out", "back.counts", "--counts_only"], str(tmp_path))
+    assert r.returncode == 0 and b"Loading precomputed file OUT.colate_mat" in r.stderr, r.stderr.decode()[-500:]
+    grid, csh, cns = gl.read_counts(tmp_path / "back.counts", B)
+    assert np.array_equal(grid, ol.age_grid()) and np.array_equal(csh, c["csh"]) and np.array_equal(cns, c["cns"])

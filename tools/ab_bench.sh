@@ -1,13 +1,13 @@
 #!/bin/bash
-# A/B two builds of libcolate_amd.so on the same box, alternating, N rounds:
-#   tools/ab_bench.sh colate_amd/lib_a/libcolate_amd.so colate_amd/lib_b/libcolate_amd.so [bench args...]
-set -e
-A=$1; B=$2; shift 2
-cp colate_amd/lib/libcolate_amd.so /tmp/orig.so
-for r in 1 2 3 4; do
-  for v in A B; do
-    if [ $v = A ]; then cp $A colate_amd/lib/libcolate_amd.so; else cp $B colate_amd/lib/libcolate_amd.so; fi
-    python bench.py --no-cpu-baseline --no-host-path --steps 30 --warmup 5 "$@" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value']), 'rep/s', round(d['roofline']['kernel_ms'],4),'ms')"
+# A/B any number of builds of libcolate_amd.so on the same GPU box, alternating, 3 rounds (device clocks differ by
+# several per cent between boxes, so only same-box comparisons mean anything):
+#   tools/ab_bench.sh lib1.so lib2.so ... -- [bench args]
+# The builds are selected through COLATE_AMD_LIB (colate_amd/_lib.py); the product library is never overwritten.
+set -euo pipefail
+libs=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do libs+=("$1"); shift; done; [ "${1:-}" = "--" ] && shift
+for r in 1 2 3; do
+  for l in "${libs[@]}"; do
+    COLATE_AMD_LIB="$(realpath "$l")" python3 bench.py --no-cpu-baseline --no-host-path --no-cxx-rccl-check --steps 30 --warmup 5 "$@" |
+      python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$l', round(d['value']), 'rep/s incl. copy+sync;', round(d['roofline']['kernel_ms'],4),'ms kernel;', d['roofline']['kernel_build'])"
   done
 done
-cp /tmp/orig.so colate_amd/lib/libcolate_amd.so
