@@ -161,6 +161,8 @@ __device__ __forceinline__ unsigned long long stamp() {
 // keeps the branch instead of if-converting it (it otherwise evaluates whole exp()/log() calls of
 // cold paths unconditionally and selects the result).
 #define COLATE_COLD() asm volatile("; cold path")
+#define COLATE_STR2(x) #x
+#define COLATE_STR(x) COLATE_STR2(x)
 
 __device__ __forceinline__ bool finite_pos(double x) { return x > 0.0 && x < __builtin_inf(); }
 
@@ -181,6 +183,25 @@ struct BinStat {
 };
 // packed form of the static part, one int per compacted position (throughput variant)
 enum { BF_F1 = 1, BF_F2 = 2, BF_F4 = 4, BF_F8 = 8, BF_TAIL = 16, BF_INRANGE = 32, BF_KB_SHIFT = 8 };
+
+// dwords of padding between the 64-byte boundary and the EM loop, per instantiation and build (see the loop head);
+// -DCOLATE_LOOP_PAD=n overrides all of them (tools/pad_sweep.sh)
+constexpr int em_loop_pad(int mode, int nch, int erows, bool tput) {
+#ifdef COLATE_LOOP_PAD
+  return (COLATE_LOOP_PAD) & 7;
+#else
+  (void)erows;
+  if (mode != 0) return 0;
+  // measured on MI355X, kernel ms for pads 0..7 (gpurun_out/r02e/pad_sweep_all.txt -> profiles/r02_placement.txt):
+#ifdef COLATE_EM_ILP_BUILD
+  (void)nch, (void)tput;
+  return 7;  // latency variant, max-ilp build: E=23 B=100 1.377 1.398 1.408 1.416 1.430 1.407 1.407 1.361; E=122 2.19 .. 2.23, 7 best
+#else
+  if (!tput) return 4;       // latency variant, default build: E=23 B=400 1.737 1.725 1.727 1.727 1.709 1.748 1.746 1.752
+  return nch == 1 ? 7 : 0;   // throughput variant: within 1 % (E=23 B=4096 8.17 .. 8.28; E=122 B=1024 3.53 .. 3.56)
+#endif
+#endif
+}
 
 // MODE 0: EM to convergence, 1: one E-step (num/den/ll out).  NCH = epoch chunks of 64 per lane;
 // EROWS = 16-lane rows of a chunk that hold epochs (1, 2 or 4; 4 whenever NCH > 1).
@@ -415,6 +436,18 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_prev = stamp();
 #endif
+  // Code placement: the time of an iteration moves by up to 5 % with the position of the loop's code relative to 32-byte
+  // instruction-fetch lines (measured: the same loop shifted in 4-byte steps has a period of 8 dwords, best to worst
+  // 1.362 .. 1.430 ms at B = 100; profiles/r02_placement.txt) -- and every edit of the prologue used to shift it.  The loop
+  // is therefore pinned to a 64-byte boundary plus em_loop_pad() dwords, tuned per instantiation on the GPU.
+  {
+    constexpr int kPad = em_loop_pad(MODE, NCH, EROWS, TPUT);
+#define COLATE_PAD_CASE(n) \
+  if constexpr (kPad == n) asm volatile(".p2align 6\n\t.rept " #n "\n\ts_nop 0\n\t.endr");
+    COLATE_PAD_CASE(0) COLATE_PAD_CASE(1) COLATE_PAD_CASE(2) COLATE_PAD_CASE(3)
+    COLATE_PAD_CASE(4) COLATE_PAD_CASE(5) COLATE_PAD_CASE(6) COLATE_PAD_CASE(7)
+#undef COLATE_PAD_CASE
+  }
   for (iter = 0; iter < max_iter; iter++) {
     COLATE_STAMP(7)
     const bool need_ll = (MODE == 1) || (iter >= p.min_iter) || (iter == max_iter - 1);

@@ -40,7 +40,8 @@ namespace {
 // (shard the replicates over GPUs 0..N-1 of the node from this one process), `--ranks N` (the same sharding as N
 // processes, one per GPU, with one RCCL all-gather of the results: run_ranked below),
 // `--counts_out FILE` (write the bootstrap count tables in the reference's .colate_mat layout,
-// 17 significant digits) and `--counts_only` (stop after that; needs no GPU).
+// 17 significant digits), `--counts_only` (stop after that; needs no GPU) and `--write_colate_mat` (write
+// <output>.colate_mat exactly as the reference does for BCF/BAM inputs, coal.cpp:3336-3343, 3453-3470).
 struct Options {
   std::map<std::string, std::string> kv;
   bool has(const std::string& k) const { return kv.count(k) > 0; }
@@ -53,7 +54,7 @@ const char* const kValueOptions[] = {
     "reference_age", "ref_genome", "anc_genome", "mask", "mask_cutoff", "chr", "bins",
     "lineage_bin", "outgroup_tmrca", "years_per_gen", "coal", "seed", "num_bootstraps", "filters",
     "groups", "poplabels", "map", "input", "output", "device", "devices", "ranks", "counts_out", "pairs"};
-const char* const kBoolOptions[] = {"help", "strandfilter", "counts_only"};
+const char* const kBoolOptions[] = {"help", "strandfilter", "counts_only", "write_colate_mat"};
 
 bool parse_options(int argc, char** argv, Options& o, std::string& err) {
   for (int i = 1; i < argc; i++) {
@@ -127,6 +128,9 @@ void print_help() {
             << "                             once and all replicates of all pairs run in one GPU launch.\n"
             << "      --counts_out arg       Optional (colate_amd): write the bootstrap count tables (.colate_mat layout).\n"
             << "      --counts_only          Optional (colate_amd): stop after --counts_out (no GPU needed).\n"
+            << "      --write_colate_mat     Optional (colate_amd): write <output>.colate_mat as the reference does for BCF/BAM inputs.\n"
+            << "      --target_table arg     (--mode make_tmp) Table `chr bp allele` of the target's calls.\n"
+            << "      --ref_genome arg       (--mode make_tmp) Reference genome fasta (per chromosome with --chr).\n"
             << "  -o, --output arg           Filename of output.\n"
             << std::endl;
 }
@@ -598,7 +602,8 @@ int run_mut(const Options& opt) {
     // the weights come from the run's mt19937 either way (coal.cpp:3350-3357); the weighted sums and
     // the F redistribution run on the GPU together with the EM unless only the counts are wanted
     // (--counts_only, no device needed) or the replicates are sharded over several GPUs
-    gpu_bootstrap = !opt.has("counts_only") && !opt.has("devices") && !(g_rank.ranked && opt.has("counts_out"));
+    gpu_bootstrap = !opt.has("counts_only") && !opt.has("devices") && !(g_rank.ranked && opt.has("counts_out")) &&
+                    !opt.has("write_colate_mat");
     if (gpu_bootstrap) {
       weights.resize((size_t)B * nb);
       if (int rc = colate_bootstrap_weights(&rng, B, nb, weights.data())) {
@@ -620,10 +625,30 @@ int run_mut(const Options& opt) {
   auto write_counts = [&]() {  // same layout as the reference's .colate_mat (coal.cpp:3336-3343, 3453-3469)
     write_counts_file(opt.get("counts_out"), B, A, age_grid, csh.data(), cns.data());
   };
+  if (opt.has("write_colate_mat") && num_blocks > 0) {
+    // coal.cpp:3336-3343, 3453-3470 (what the reference does when its inputs are BCF/BAM files): the counts are divided
+    // by 1e3 IN PLACE -- the EM then runs on the scaled tables -- and written with the stream's default 6 significant
+    // digits: grid line, then per replicate a line of shared and a line of not-shared counts.  The file is what a later
+    // run (ours or the reference's) picks up as "precomputed file" (coal.cpp:3471-3499).
+    const double norm = 1e3;
+    for (double& v : csh) v /= norm;
+    for (double& v : cns) v /= norm;
+    if (g_rank.rank == 0) {
+      std::ofstream os_mat(mat);
+      for (int b = 0; b < A; b++) os_mat << age_grid[b] << " ";
+      os_mat << "\n";
+      for (int i = 0; i < B; i++) {
+        for (int b = 0; b < A; b++) os_mat << csh[(size_t)i * A + b] << " ";
+        os_mat << "\n";
+        for (int b = 0; b < A; b++) os_mat << cns[(size_t)i * A + b] << " ";
+        os_mat << "\n";
+      }
+    }
+  }
   if (opt.has("counts_out") && !gpu_bootstrap) {
     if (g_rank.rank == 0) write_counts();
-    if (opt.has("counts_only")) return 0;
   }
+  if (opt.has("counts_only")) return 0;
 
   // ---- epochs (coal.cpp:3501-3646)
   std::vector<double> epochs(COLATE_MAX_EPOCHS), init_rates(COLATE_MAX_EPOCHS, COLATE_DEFAULT_INIT_RATE);
@@ -955,6 +980,145 @@ int run_mut_pairs(const Options& opt) {
   return 0;
 }
 
+// ------------------------------------------------------------------ --mode make_tmp --target_table
+// The htslib-free input of the reference's make_tmp (coal.cpp:2923-3069 -> maketmp_table, coal.cpp:2682-2808): a text
+// table `chr bp allele` of the target's haploid calls becomes the binary .colate.in stream `--mode mut` reads
+// (record layout coal.cpp:2505-2514).  BCF and BAM inputs (maketmp_vcf / maketmp_bam) need htslib and stay with the
+// reference build.  The table is walked with formatted extraction exactly like the reference's igzstream (a failed
+// read at the end of the file leaves the last record in place).
+int run_make_tmp(const Options& opt) {
+  if (!opt.has("mut") || !opt.has("output")) {  // coal.cpp:2929-2939
+    std::cout << "Not enough arguments supplied." << std::endl;
+    std::cout << "Needed: mut, ref_genome, output, either of target_bcf or target_bam. Optional: filters, target_mask, "
+                 "strandfilter, anc_genome."
+              << std::endl;
+    print_help();
+    std::cout << "Calculate coalescence rates for sample." << std::endl;
+    return 0;
+  }
+  std::cerr << "---------------------------------------------------------" << std::endl;
+  std::cerr << "Calculating Colate tmp input file for ";
+  if (opt.has("target_bcf") || opt.has("target_bam")) {
+    std::cerr << std::endl
+              << "Error: colate_amd's make_tmp reads --target_table only; BCF/BAM inputs need htslib (reference build)."
+              << std::endl;
+    return 1;
+  }
+  if (!opt.has("target_table")) {  // (the reference falls through and writes nothing)
+    std::cerr << std::endl << "Error: --mode make_tmp needs --target_table." << std::endl;
+    return 1;
+  }
+  if (!opt.has("ref_genome")) {  // cxxopts throws on options["ref_genome"].as<std::string>() (coal.cpp:3027, 3037)
+    std::cerr << std::endl << "Error: --mode make_tmp --target_table needs --ref_genome." << std::endl;
+    return 1;
+  }
+  std::cerr << opt.get("target_table") << ".." << std::endl;
+  std::vector<std::string> names, mut_files, ref_genomes, tmasks;
+  if (opt.has("chr")) {  // coal.cpp:3018-3032
+    GzText is_chr;
+    if (!is_chr.open(opt.get("chr"))) std::cerr << "Error while opening file " << opt.get("chr") << std::endl;
+    std::string line;
+    while (is_chr.getline(line)) {
+      names.push_back(line);
+      mut_files.push_back(opt.get("mut") + "_chr" + line + ".mut");
+      ref_genomes.push_back(opt.get("ref_genome") + "_chr" + line + ".fa");
+      if (opt.has("target_mask")) tmasks.push_back(opt.get("target_mask") + "_chr" + line + ".fa");
+    }
+  } else {
+    names.push_back("");
+    mut_files.push_back(opt.get("mut"));
+    ref_genomes.push_back(opt.get("ref_genome"));
+    if (opt.has("target_mask")) tmasks.push_back(opt.get("target_mask"));
+  }
+  const std::string out_name = opt.get("output") + ".colate.in";
+  FILE* fp = std::fopen(out_name.c_str(), "wb");
+  if (!fp) {
+    std::cerr << "Error: cannot write " << out_name << std::endl;
+    return 1;
+  }
+  std::istringstream is;
+  {
+    GzText table;
+    if (!table.open(opt.get("target_table"))) {  // coal.cpp:2699-2702
+      std::cerr << "Error while opening file " << opt.get("target_table") << std::endl;
+      return 1;
+    }
+    std::string all, line;
+    while (table.getline(line)) {
+      all += line;
+      all += '\n';
+    }
+    is.str(all);
+  }
+  const bool has_tar_mask = !tmasks.empty();
+  std::string chr_table, allele, ancestral, derived;
+  int bp_target = -1;
+  const int N_target = 1;
+  for (size_t chr = 0; chr < mut_files.size(); chr++) {
+    std::cerr << "parsing CHR: " << chr + 1 << " / " << mut_files.size() << std::endl;
+    std::string tar_mask, ref_genome;
+    if (has_tar_mask) read_fasta_mask(tmasks[chr], tar_mask);
+    std::vector<MutRow> rows;
+    read_mut_file(mut_files[chr], rows);
+    read_fasta_mask(ref_genomes[chr], ref_genome);  // read (and required to exist) as in the reference; only its presence matters
+    if (bp_target == -1) is >> chr_table >> bp_target >> allele;
+    while (chr_table != names[chr]) {
+      if (!(is >> chr_table >> bp_target >> allele)) break;
+    }
+    for (const MutRow& m : rows) {
+      if (m.flipped != 0 || m.num_branches != 1) continue;
+      size_t i = 0;
+      ancestral.clear();
+      derived.clear();
+      while (i < m.mutation_type.size() && m.mutation_type[i] != '/') ancestral.push_back(m.mutation_type[i++]);
+      i++;
+      while (i < m.mutation_type.size()) derived.push_back(m.mutation_type[i++]);
+      const int bp_mut = m.pos;
+      if (ancestral.empty() || derived.empty()) continue;
+      bool use = true;
+      if (ancestral != "A" && ancestral != "C" && ancestral != "G" && ancestral != "T" && ancestral != "0") use = false;
+      if (derived != "A" && derived != "C" && derived != "G" && derived != "T" && derived != "1") use = false;
+      if (has_tar_mask) {  // coal.cpp:2749-2755: sites beyond the mask are dropped here (unlike in parse_tmptmp)
+        if (bp_mut >= (int)tar_mask.size())
+          use = false;
+        else if (bp_mut < 1 || tar_mask[bp_mut - 1] != 'P')
+          use = false;
+      }
+      if (!use) continue;
+      if (chr_table == names[chr] && bp_target < bp_mut) {
+        while (!is.eof() && chr_table == names[chr] && bp_target < bp_mut) is >> chr_table >> bp_target >> allele;
+      }
+      int DAF_target = 0;
+      if (chr_table == names[chr] && bp_target == bp_mut) {  // the target has a call here (coal.cpp:2768-2782)
+        if (allele == derived || allele == ancestral) {
+          if (allele == derived) DAF_target = 1;
+        } else {
+          use = false;
+        }
+      } else {
+        use = false;
+      }
+      if (!use) continue;
+      const int lchrom = (int)names[chr].size();
+      const int AAF_target = N_target - DAF_target;
+      std::fwrite(&lchrom, sizeof(int), 1, fp);
+      std::fwrite(names[chr].c_str(), sizeof(char), (size_t)lchrom, fp);
+      std::fwrite(&bp_mut, sizeof(int), 1, fp);
+      std::fwrite(&ancestral[0], sizeof(char), 1, fp);
+      std::fwrite(&derived[0], sizeof(char), 1, fp);
+      std::fwrite(&AAF_target, sizeof(int), 1, fp);
+      std::fwrite(&DAF_target, sizeof(int), 1, fp);
+    }
+  }
+  std::fclose(fp);
+  rusage usage;  // coal.cpp:3055-3067
+  getrusage(RUSAGE_SELF, &usage);
+  std::cerr << "CPU Time spent: " << usage.ru_utime.tv_sec << "." << std::setfill('0') << std::setw(6)
+            << usage.ru_utime.tv_usec << "s; Max Memory usage: " << usage.ru_maxrss / 1000.0 << "Mb." << std::endl;
+  std::cerr << "---------------------------------------------------------" << std::endl << std::endl;
+  return 0;
+}
+
 // `--ranks N`: fork N processes BEFORE anything touches the GPU (this process never does), one per GPU; each runs the
 // whole `--mode mut` pipeline (same inputs, same --seed, hence the same tables and bootstrap weights), computes its
 // contiguous range of replicates and takes part in one RCCL all-gather (colate_comm.cpp); rank 0 writes the outputs.
@@ -1077,9 +1241,17 @@ extern "C" int colate_mut_main(int argc, char** argv) {
       return 1;
     }
   }
+  if (mode == "make_tmp") {
+    try {
+      return run_make_tmp(opt);
+    } catch (const std::exception& e) {
+      std::cerr << "Error: " << e.what() << std::endl;
+      return 1;
+    }
+  }
   std::cout << "####### error #######" << std::endl;
-  std::cout << "colate_amd implements --mode mut only (preprocess_mut, make_tmp, calc_depth, "
-               "print_tmp, CondCoalRates stay with the reference build)."
+  std::cout << "colate_amd implements --mode mut and --mode make_tmp --target_table (preprocess_mut, make_tmp from "
+               "BCF/BAM, calc_depth, print_tmp, CondCoalRates stay with the reference build)."
             << std::endl;
   return 1;
 }

@@ -1,0 +1,53 @@
+// colate_amd/csrc/tools/no_device_stubs.cpp -- ONLY for the host sanitizer binary (`make asan` -> bin/Colate_asan):
+// the host side of the library (mut_host.cpp, mut_driver.cpp) built with g++ -fsanitize=address,undefined, without
+// HIP.  Every compute entry point that needs a device is defined here to FAIL with COLATE_ENODEVICE -- the sanitizer
+// runs cover the readers, the table fill, the bootstrap, make_tmp and the writers (--counts_only); nothing here
+// computes anything, and libcolate_amd.so does not contain this file.
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "colate_amd.h"
+#include "colate_internal.h"
+
+namespace colate {
+static thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+}  // namespace colate
+
+static int nodev() { return colate::fail(COLATE_ENODEVICE, "host sanitizer build: no device code linked"); }
+
+extern "C" {
+const char* colate_version(void) { return "colate_amd host sanitizer build (no device code)"; }
+const char* colate_last_error(void) { return colate::g_err.c_str(); }
+int colate_device_count(void) { return nodev(); }
+int colate_set_device(int) { return nodev(); }
+int colate_em_batch(int, int, int, const double*, const double*, const double*, const double*, const double*, int, int,
+                    double, double, double*, int*, double*, int*) { return nodev(); }
+int colate_em_batch_rows(int, int, int, const double*, const double*, const double*, const double*, const double*, int, int,
+                         double, double, double*, int*, double*, int*) { return nodev(); }
+int colate_em_batch_sharded(int, const int*, int, int, int, const double*, const double*, const double*, const double*,
+                            const double*, int, int, double, double, double*, int*, double*, int*) { return nodev(); }
+int colate_em_batch_rows_sharded(int, const int*, int, int, int, const double*, const double*, const double*, const double*,
+                                 const double*, int, int, double, double, double*, int*, double*, int*) { return nodev(); }
+int colate_bootstrap_em_batch(int, int, int, int, const double*, double, const double*, const double*, const double*,
+                              const double*, const double*, const double*, const double*, int, int, double, double, double*,
+                              int*, double*, int*, double*, double*) { return nodev(); }
+int colate_shard_bounds(int, int, int, int*, int*) { return nodev(); }
+int colate_comm_unique_id(void*) { return nodev(); }
+int colate_comm_create(const void*, int, int, void**) { return nodev(); }
+int colate_comm_destroy(void*) { return COLATE_OK; }
+int colate_em_batch_allgather(void*, int, int, int, const double*, const double*, const double*, const double*, const double*,
+                              int, int, double, double, double*, int*, double*, int*) { return nodev(); }
+int colate_bootstrap_em_batch_allgather(void*, int, int, int, int, const double*, double, const double*, const double*,
+                                        const double*, const double*, const double*, const double*, const double*, int, int,
+                                        double, double, double*, int*, double*, int*) { return nodev(); }
+}

@@ -208,8 +208,85 @@ def _isnum(t):
         return False
 
 
+def make_l4():
+    """Rows f4 of SURVEY.md section 8 that need no htslib: `--mode make_tmp --target_table` (coal.cpp:2682-2808, 2923-3069)
+    and the .colate_mat the reference writes for BCF/BAM inputs (coal.cpp:3336-3343, 3453-3470; format pinned by the
+    reference READING the file our CLI wrote, coal.cpp:3471-3499)."""
+    import golden_lib
+
+    CLI = os.path.join(ROOT, "colate_amd", "bin", "Colate")
+    # ---- make_tmp from a table of haploid calls, on the .mut files and target masks of l3_masks
+    d = os.path.join(HERE, "l4_maketmp")
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    with tempfile.TemporaryDirectory() as work:
+        golden_lib.l3_stage("l3_masks", work)
+        rng = np.random.default_rng(77)
+        rows = []
+        for chrom in ("1", "2"):
+            with gzip.open(os.path.join(work, f"P_chr{chrom}.mut.gz"), "rt") as f:
+                next(f)
+                for line in f:
+                    t = line.split(";")
+                    bp, (anc, der) = int(t[1]), (t[10].split("/") + [""])[:2]
+                    u = rng.uniform()
+                    if u < 0.8:  # the target has a call at this site: ancestral, derived or (rarely) a third allele
+                        v = rng.uniform()
+                        allele = der if v < 0.45 else (anc if v < 0.9 else "ACGT"[rng.integers(4)])
+                        rows.append(f"{chrom} {bp} {allele}")
+                    if rng.uniform() < 0.15:  # calls at sites without a dated mutation
+                        rows.append(f"{chrom} {bp + 1} {'ACGT'[rng.integers(4)]}")
+        table = "\n".join(rows) + "\n"
+        with gzip.GzipFile(os.path.join(d, "table.txt.gz"), "wb", mtime=0) as g:
+            g.write(table.encode())
+        open(os.path.join(work, "table.txt"), "w").write(table)
+        for chrom in ("1", "2"):  # the reference opens (and requires) the reference genome; only its presence matters here
+            for where in (d, work):
+                open(os.path.join(where, f"G_chr{chrom}.fa"), "w").write(f">chr{chrom}\nACGTACGTNN\n")
+        args = ["--mode", "make_tmp", "--mut", "P", "--chr", "chr.txt", "--target_table", "table.txt", "--ref_genome", "G",
+                "--target_mask", "TM", "-o", "expected"]
+        r = subprocess.run([REF_BIN] + args, cwd=work, capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()[-1000:]
+        blob = open(os.path.join(work, "expected.colate.in"), "rb").read()
+        with gzip.GzipFile(os.path.join(d, "expected.colate.in.gz"), "wb", mtime=0) as g:
+            g.write(blob)
+        # and the same without the mask (other branch of coal.cpp:2749)
+        args2 = [a for i, a in enumerate(args) if a != "--target_mask" and (i == 0 or args[i - 1] != "--target_mask")]
+        args2[args2.index("-o") + 1] = "expected_nomask"
+        r = subprocess.run([REF_BIN] + args2, cwd=work, capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()[-1000:]
+        blob2 = open(os.path.join(work, "expected_nomask.colate.in"), "rb").read()
+        with gzip.GzipFile(os.path.join(d, "expected_nomask.colate.in.gz"), "wb", mtime=0) as g:
+            g.write(blob2)
+    json.dump({"generator": "tests/golden/make_golden.py (oracle/_ref/Colate_ref --mode make_tmp)", "inputs_from": "l3_masks",
+               "args": args, "args_nomask": args2, "records": len(blob) // 18, "records_nomask": len(blob2) // 18},
+              open(os.path.join(d, "case.json"), "w"))
+    print(f"l4_maketmp: {len(blob) // 18} records with mask, {len(blob2) // 18} without")
+    # ---- .colate_mat written by OUR CLI (--write_colate_mat) and read by the REFERENCE
+    d = os.path.join(HERE, "l4_colate_mat")
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    with tempfile.TemporaryDirectory() as work:
+        case = golden_lib.l3_stage("l3_modern", work)
+        args = list(case["args"])
+        args[args.index("-o") + 1] = "OUT"
+        r = subprocess.run([CLI] + args + ["--write_colate_mat", "--counts_only"], cwd=work, capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()[-1000:]
+        shutil.copy(os.path.join(work, "OUT.colate_mat"), os.path.join(d, "OUT.colate_mat"))
+        B = args[args.index("--num_bootstraps") + 1]
+        ref_args = ["--mode", "mut", "--mut", "dummy", "--bins", args[args.index("--bins") + 1], "--num_bootstraps", B, "-o", "OUT"]
+        err, iters = run_ref(ref_args, work)
+        assert "Loading precomputed file" in err
+        shutil.copy(os.path.join(work, "OUT.coal"), os.path.join(d, "expected.coal"))
+    json.dump({"generator": "tests/golden/make_golden.py (our CLI --write_colate_mat, then oracle/_ref/Colate_ref on that file)",
+               "inputs_from": "l3_modern", "writer_args": args + ["--write_colate_mat", "--counts_only"], "reader_args": ref_args,
+               "iterations": iters}, open(os.path.join(d, "case.json"), "w"))
+    print(f"l4_colate_mat: iterations={iters}")
+
+
 if __name__ == "__main__":
     assert os.path.exists(REF_BIN), "oracle/_ref/Colate_ref missing: make -C oracle ref (needs /root/reference)"
     make_l1()
     make_l2()
     make_l3()
+    make_l4()

@@ -111,6 +111,28 @@ def test_colate_mat_hook_three_way(ca, name, tmp_path):
         assert m_tok[: 2 + ep.size - k_cli] == r_tok[: 2 + ep.size - k_cli]
 
 
+def test_colate_mat_written_by_us_read_by_both(ca, tmp_path):
+    """The 6-digit, /1e3 .colate_mat of --write_colate_mat (tests/golden/l4_colate_mat: written by our CLI, read by the
+    reference binary when the fixture was made): our CLI loads the same file and prints the reference's .coal."""
+    import json
+    import shutil
+
+    src = os.path.join(gl.HERE, "l4_colate_mat")
+    case = json.load(open(os.path.join(src, "case.json")))
+    shutil.copy(os.path.join(src, "OUT.colate_mat"), str(tmp_path / "OUT.colate_mat"))
+    r = subprocess.run([CLI] + case["reader_args"], cwd=str(tmp_path), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    err = r.stderr.decode()
+    assert [int(l.rsplit(" ", 1)[1]) for l in err.split("\n") if l.startswith("Bootstrap ")] == case["iterations"]
+    mine = (tmp_path / "OUT.coal").read_text().split("\n")
+    ref = open(os.path.join(src, "expected.coal")).read().split("\n")
+    note = [l for l in err.split("\n") if l.startswith("Note: the last ")]
+    k_cli = int(note[0].split()[3]) if note else 0
+    assert mine[:2] == ref[:2] and len(mine) == len(ref) and k_cli <= 4
+    for m, t in zip(mine[2:], ref[2:]):
+        assert m.split()[: 2 + 23 - k_cli] == t.split()[: 2 + 23 - k_cli]
+
+
 @pytest.mark.parametrize("name", gl.l3_names())
 def test_l3_cli_drop_in(ca, name, tmp_path):
     """`Colate --mode mut` of colate_amd on the reference's input files and --seed: same stderr
@@ -145,7 +167,7 @@ def test_l3_cli_drop_in(ca, name, tmp_path):
     # reference's own rate there moves by ~1 % under libm noise (stable_mask).  Everything the checker finds pinned must
     # be the reference's token; the CLI's note must cover at least the epochs the checker finds unstable.
     unstable = ep.size - mask.sum(axis=1)
-    assert mask.mean() > 0.9
+    assert mask.mean() > 0.85
     note = [l for l in err.split("\n") if l.startswith("Note: the last ")]
     k_cli = int(note[0].split()[3]) if note else 0
     assert unstable.max() <= k_cli <= unstable.max() + 3, (k_cli, unstable)

@@ -2,6 +2,7 @@
 mut() around the EM (age grid, epochs, block bootstrap + F redistribution, .coal writer, readers) and
 the full CLI up to the count tables, checked against the oracle and the golden fixtures."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -182,8 +183,10 @@ def test_cli_option_errors(tmp_path):
     assert r.returncode != 0 and b"does not exist" in r.stderr
     r = _run_cli(["--mode", "mut"], str(tmp_path))
     assert b"Not enough arguments supplied." in r.stdout
-    r = _run_cli(["--mode", "make_tmp"], str(tmp_path))
+    r = _run_cli(["--mode", "preprocess_mut"], str(tmp_path))
     assert r.returncode != 0
+    r = _run_cli(["--mode", "make_tmp", "--mut", "P", "-o", "x", "--target_bcf", "y"], str(tmp_path))
+    assert r.returncode != 0 and b"htslib" in r.stderr
     # README spelling --num_bootstrap is accepted (the reference only knows --num_bootstraps)
     case = gl.l3_stage("l3_nochr", str(tmp_path))
     args = [("--num_bootstrap" if a == "--num_bootstraps" else a) for a in case["args"]]
@@ -257,3 +260,70 @@ def test_colate_mat_loader_round_trip(name, tmp_path):
     assert r.returncode == 0 and b"Loading precomputed file OUT.colate_mat" in r.stderr, r.stderr.decode()[-500:]
     grid, csh, cns = gl.read_counts(tmp_path / "back.counts", B)
     assert np.array_equal(grid, ol.age_grid()) and np.array_equal(csh, c["csh"]) and np.array_equal(cns, c["cns"])
+
+
+@pytest.mark.parametrize("which", ["args", "args_nomask"])
+def test_make_tmp_from_table_matches_reference(which, tmp_path):
+    """`--mode make_tmp --target_table` (coal.cpp:2682-2808, 2923-3069): the .colate.in our CLI writes from a table of
+    haploid calls is byte for byte the reference's, with and without a target mask."""
+    import gzip
+    import shutil
+
+    gl.l3_stage("l3_masks", str(tmp_path))
+    src = os.path.join(gl.HERE, "l4_maketmp")
+    case = json.load(open(os.path.join(src, "case.json")))
+    with gzip.open(os.path.join(src, "table.txt.gz"), "rb") as g:
+        (tmp_path / "table.txt").write_bytes(g.read())
+    for f in ("G_chr1.fa", "G_chr2.fa"):
+        shutil.copy(os.path.join(src, f), str(tmp_path / f))
+    args = list(case[which])
+    out = args[args.index("-o") + 1]
+    args[args.index("-o") + 1] = "mine"
+    r = _run_cli(args, str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    assert b"parsing CHR: 2 / 2" in r.stderr
+    with gzip.open(os.path.join(src, out + ".colate.in.gz"), "rb") as g:
+        want = g.read()
+    got = (tmp_path / "mine.colate.in").read_bytes()
+    assert len(want) > 18 * 1000 and got == want
+
+
+def test_make_tmp_output_feeds_mode_mut(tmp_path):
+    """The two halves together: make_tmp's .colate.in as --target_tmp of `--mode mut` (tables only, no GPU here)."""
+    import gzip
+    import shutil
+
+    gl.l3_stage("l3_masks", str(tmp_path))
+    src = os.path.join(gl.HERE, "l4_maketmp")
+    with gzip.open(os.path.join(src, "table.txt.gz"), "rb") as g:
+        (tmp_path / "table.txt").write_bytes(g.read())
+    for f in ("G_chr1.fa", "G_chr2.fa"):
+        shutil.copy(os.path.join(src, f), str(tmp_path / f))
+    r = _run_cli(["--mode", "make_tmp", "--mut", "P", "--chr", "chr.txt", "--target_table", "table.txt", "--ref_genome", "G",
+                  "-o", "T2"], str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-500:]
+    r = _run_cli(["--mode", "mut", "--mut", "P", "--chr", "chr.txt", "--target_tmp", "T2.colate.in", "--reference_tmp",
+                  "R.colate.in", "--bins", "3,7,0.2", "--seed", "2", "--num_bootstraps", "2", "-o", "x", "--counts_out",
+                  "x.counts", "--counts_only"], str(tmp_path))
+    assert r.returncode == 0 and b"Number of blocks: 2" in r.stderr, r.stderr.decode()[-500:]
+    _, csh, cns = gl.read_counts(tmp_path / "x.counts", 2)
+    assert csh.sum() > 0 and cns.sum() > 0
+
+
+def test_colate_mat_writer_is_read_by_the_reference(tmp_path):
+    """--write_colate_mat (what the reference writes for BCF/BAM inputs, coal.cpp:3336-3343, 3453-3470: counts / 1e3,
+    6 significant digits): our CLI reproduces the committed file, which the reference binary loaded as "precomputed
+    file" (coal.cpp:3471-3499) when the fixture was made; the oracle's EM on the file's numbers prints the reference's
+    .coal."""
+    src = os.path.join(gl.HERE, "l4_colate_mat")
+    case = json.load(open(os.path.join(src, "case.json")))
+    gl.l3_stage("l3_modern", str(tmp_path))
+    r = _run_cli(case["writer_args"], str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    assert (tmp_path / "OUT.colate_mat").read_text() == open(os.path.join(src, "OUT.colate_mat")).read()
+    B = len(case["iterations"])
+    grid, csh, cns = gl.read_counts(tmp_path / "OUT.colate_mat", B)
+    ep, _ = ol.epochs_from_bins("3,7,0.2")
+    rates, iters, _, _ = ol.em_batch(grid, csh, cns, ep)
+    assert iters.tolist() == case["iterations"]
+    assert gl.coal_text(ep, rates) == open(os.path.join(src, "expected.coal")).read()
