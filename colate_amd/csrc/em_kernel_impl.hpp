@@ -56,7 +56,7 @@ namespace {
 
 constexpr int kWave = 64;
 enum { O_W = 0, O_N, O_D, kNumBinArrays };  // per-bin values -> epochs: weight (c r | c u), own-epoch num, denom
-enum { G_LAM = 0, G_INV, G_XA, G_P, G_BETA, G_CS, G_S, G_PW, kNumGather };  // per-epoch values in LDS
+enum { G_LAM = 0, G_INV, G_XA, G_P, G_BETA, G_CS, G_S, G_PW, G_INIT, kNumGather };  // per-epoch values in LDS (G_INIT: starting rates, static)
 
 // ----------------------------------------------------------------- lane plumbing
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   double* s_nd = s_out + 2 * kNumBinArrays * APZ;    // [2 roles][2][EPAD] partial N, D per role
   double* s_cfail = s_nd + 4 * EPAD;                 // [2 roles][APZ] counts of bins whose normaliser failed
   double* s_cnt = s_cfail + 2 * APZ;                 // [2 roles][APZ] counts
-  double* s_ll = s_cnt + 2 * APZ;                    // [8] per-wave log-likelihood partials + [2] total counts per kind
-  double* s_age = s_ll + 10;                         // [AP] age grid (throughput variant)
+  double* s_ll = s_cnt + 2 * APZ;                    // [8] per-wave log-likelihood partials + [2] total counts per kind + oldest data epoch
+  double* s_age = s_ll + 12;                         // [AP] age grid (throughput variant)
   int* s_kb = reinterpret_cast<int*>(s_age + AP);    // [AP + 1] epoch of each bin
   int* s_fail = s_kb + AP + 1;                       // [8] per-wave "a bin failed" flags
   int* s_misc = s_fail + 8;                          // [4] nzlo, nzhi, flags
@@ -313,8 +313,10 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         vstat[c] = true;
       }
       lam_e[c] = p.rates_in[(size_t)rep * p.rates_stride + e];
+      if (wave == 0) s_ep[G_INIT * EPAD + e] = lam_e[c];  // kept for the epilogue's verdict
     }
   }
+  if (tid == 0) s_ll[10] = (nzhi > nzlo) ? (double)s_kb[nzhi - 1] : -1.0;  // epoch of the oldest bin that carries data
   // bin statics: this lane's bin (compacted to the bins that carry data) and role
   const int pos = grp * kWave + lane;  // position in the compacted tile
   const int bin = nzlo + pos;
@@ -425,6 +427,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   (void)nwave_live;
 
   int my_flags = 0;
+  int ever_copied[NCH];  // this lane's epoch had num == 0 ("copy the previous rate", coal.cpp:3779-3788) in some iteration
+#pragma unroll
+  for (int c = 0; c < NCH; c++) ever_copied[c] = 0;
   bool wrote_fail = false, flag_set = false;
   const double thr = 1.0 - p.rel_tol;
   double ll = -__builtin_inf(), prev_ll = -__builtin_inf();  // coal.cpp:3685
@@ -875,6 +880,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         const bool copy = (N_e[c] == 0);
+        ever_copied[c] |= copy ? 1 : 0;  // (for the epilogue's verdict; off the dependency chain)
         cand[c] = lam_e[c];
         if (!copy && D_e[c] != 0) {
 #if COLATE_ABL_HAS(10)
@@ -966,8 +972,20 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     for (int c = NCH - 1; c >= 0; c--) {
       const int e = c * kWave + lane;
       const double D = s_nd[1 * EPAD + e] + s_nd[3 * EPAD + e];  // denominators of the last E-step
+      const double Nfin = s_nd[0 * EPAD + e] + s_nd[2 * EPAD + e];
       const double eta = dt_e[c] * (kIntegResidue * (s_ll[8] + s_ll[9]));  // dt_e * residue of ALL bins (both kinds); 0 in the last epoch and beyond E
-      const bool resolved = D >= kResolvedRatio * eta || (lam_e[c] <= p.rate_floor && D < 3.0 * eta);
+      // A numerator that was exactly 0 in some iterations (underflow: the rate copied its neighbour's, coal.cpp:3779-3788)
+      // and is not at the end leaves the rate at whatever the neighbour was when the underflow ended -- a snapshot that
+      // depends on the last bits of exp(); an epoch that copies to the end, or never did, is fine.
+      const bool snapshot = ever_copied[c] != 0 && Nfin != 0.0;
+      // An epoch that starts after the oldest bin with data: every contribution to its statistics has num/denom equal to
+      // the current rate (the likelihood does not depend on it), so the EM leaves it where it is -- normally at its starting
+      // value, which every build prints alike.  If it has moved, rounding moved it (early iterations far from the optimum),
+      // and the reference's own value is as arbitrary (tests/golden/l3_coal_modern: 42 % under 1-ulp libm noise).
+      const double init = s_ep[G_INIT * EPAD + e];
+      const bool drifted = (double)e > s_ll[10] && !(__builtin_fabs(lam_e[c] - init) <= 1e-9 * init);
+      const bool resolved = !ep_on[c] || (!snapshot && !drifted &&
+                            (D >= kResolvedRatio * eta || (lam_e[c] <= p.rate_floor && D < 3.0 * eta)));
       const unsigned long long bad = __ballot(!resolved);
       if (bad) first_bad = c * kWave + __builtin_ctzll(bad);
     }
@@ -1009,7 +1027,7 @@ inline size_t em_lds_bytes(int E, int A) {
   const size_t EPAD = (size_t)em_chunks(E) * kWave;
   const size_t AP = (size_t)em_groups(A) * kWave;
   const size_t APZ = AP + 16;
-  const size_t doubles = (EPAD + 1) + kNumGather * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ + 10 + AP;
+  const size_t doubles = (EPAD + 1) + kNumGather * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ + 12 + AP;
   const size_t ints = (AP + 1) + 8 + 4 + AP;
   return doubles * sizeof(double) + ints * sizeof(int);
 }

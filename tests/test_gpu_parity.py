@@ -166,6 +166,25 @@ def test_sparse_tables_and_the_integ_residue(ca):
         assert (r1[b, 1:][f] == 5e-9).all()
 
 
+def test_underflow_snapshot_epoch_is_flagged(ca):
+    """A replicate whose last epoch's numerator underflows to exactly 0 for a few hundred iterations ("num == 0: copy the
+    previous rate", coal.cpp:3779-3788) and recovers: the rate freezes at whatever its neighbour was at that moment --
+    the oracle's own value moves by tens of per cent under 1-ulp libm noise.  The kernel must not call it resolved."""
+    from colate_amd import workloads
+
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins("3,7,0.2")
+    csh, cns = workloads.sparse_tables(grid, 192)
+    csh, cns = csh[82:83], cns[82:83]
+    r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep)
+    r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep)
+    assert (it0 == it1).all() and (ca.status_flags(fl1) == 0).all()
+    mask = ol.stable_mask(grid, csh, cns, ep, r0)
+    assert not mask[0, -1]  # the checker sees it
+    unres, unstable = ol.check_rates(r1, fl1, r0, mask, RATE_RTOL)
+    assert unres[0] >= 1  # ... and so does the kernel
+
+
 def test_coal_EM_mirror_reference_unit_test(ca):
     """Restates TEST_CASE("test EM expectation step") (include/test/test_aDNA.cpp:68-212) with the
     GPU class in place of coal_EM and the oracle in place of coal_EM_simplified, at 1e-9 instead of
