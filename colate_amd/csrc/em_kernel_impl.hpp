@@ -194,12 +194,24 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput) {
   if (mode != 0) return 0;
   // measured on MI355X, kernel ms for pads 0..7 (gpurun_out/r02e/pad_sweep_all.txt -> profiles/r02_placement.txt):
 #ifdef COLATE_EM_ILP_BUILD
-  (void)nch, (void)tput;
-  return 7;  // latency variant, max-ilp build: E=23 B=100 1.377 1.398 1.408 1.416 1.430 1.407 1.407 1.361; E=122 2.19 .. 2.23, 7 best
+  (void)tput;
+  // latency variant, max-ilp build (code of round 2's final loop): E=23 B=100 1.404 1.424 1.405 1.462 1.394 1.403 1.419 1.431
+  // (+ second point, em_loop_pad2: 1.378); E=122 B=100 2.238 2.249 2.220 2.199 2.210 2.221 2.207 2.218
+  return nch == 1 ? 4 : 3;
 #else
   if (!tput) return 4;       // latency variant, default build: E=23 B=400 1.737 1.725 1.727 1.727 1.709 1.748 1.746 1.752
   return nch == 1 ? 7 : 0;   // throughput variant: within 1 % (E=23 B=4096 8.17 .. 8.28; E=122 B=1024 3.53 .. 3.56)
 #endif
+#endif
+}
+
+// A second placement point behind barrier 2 (a 32-byte boundary + this many dwords), or -1 for none
+constexpr int em_loop_pad2(int mode, int nch, bool tput) {
+#if defined(COLATE_EM_ILP_BUILD) && !defined(COLATE_LOOP_PAD)
+  return (mode == 0 && nch == 1 && !tput) ? 4 : -1;  // pads 0..7 at E=23 B=100: 1.405 1.385 1.413 1.444 1.378 1.415 1.412 1.411
+#else
+  (void)mode, (void)nch, (void)tput;
+  return -1;
 #endif
 }
 
@@ -427,7 +439,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   (void)nwave_live;
 
   int my_flags = 0;
-  int ever_copied[NCH];  // this lane's epoch had num == 0 ("copy the previous rate", coal.cpp:3779-3788) in some iteration
+  unsigned long long ever_copied[NCH];  // bit l: epoch l of the chunk had num == 0 ("copy the previous rate", coal.cpp:3779-3788) in some iteration
 #pragma unroll
   for (int c = 0; c < NCH; c++) ever_copied[c] = 0;
   bool wrote_fail = false, flag_set = false;
@@ -711,6 +723,11 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     }
     COLATE_STAMP(2)
     __syncthreads();  // ---- barrier 2: per-bin tails visible
+    if constexpr (em_loop_pad2(MODE, NCH, TPUT) >= 0) {
+      // second placement point (these few s_nop are executed every iteration; they pay for themselves: 1.391 -> 1.378 ms)
+      static_assert(em_loop_pad2(MODE, NCH, TPUT) < 0 || em_loop_pad2(MODE, NCH, TPUT) == 4, "add the asm for another pad");
+      asm volatile(".p2align 5\n\t.rept 4\n\ts_nop 0\n\t.endr");
+    }
     COLATE_STAMP(3)
     // ============================================================ P3: per-epoch sums (role leaders)
     if (leader && !COLATE_ABL_HAS(13)) {
@@ -880,7 +897,6 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         const bool copy = (N_e[c] == 0);
-        ever_copied[c] |= copy ? 1 : 0;  // (for the epilogue's verdict; off the dependency chain)
         cand[c] = lam_e[c];
         if (!copy && D_e[c] != 0) {
 #if COLATE_ABL_HAS(10)
@@ -892,6 +908,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         }
         keep[c] = __ballot(ep_on[c] && !copy);
         const unsigned long long cp = __ballot(ep_on[c] && copy);
+        ever_copied[c] |= cp;  // (scalar; for the epilogue's verdict)
         if (cp && (lower_keep || (cp & (cp + 1ull)))) simple = false;
         if (keep[c]) lower_keep = true;
       }
@@ -977,7 +994,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       // A numerator that was exactly 0 in some iterations (underflow: the rate copied its neighbour's, coal.cpp:3779-3788)
       // and is not at the end leaves the rate at whatever the neighbour was when the underflow ended -- a snapshot that
       // depends on the last bits of exp(); an epoch that copies to the end, or never did, is fine.
-      const bool snapshot = ever_copied[c] != 0 && Nfin != 0.0;
+      const bool snapshot = ((ever_copied[c] >> lane) & 1ull) && Nfin != 0.0;
       // An epoch that starts after the oldest bin with data: every contribution to its statistics has num/denom equal to
       // the current rate (the likelihood does not depend on it), so the EM leaves it where it is -- normally at its starting
       // value, which every build prints alike.  If it has moved, rounding moved it (early iterations far from the optimum),
