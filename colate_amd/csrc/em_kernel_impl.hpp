@@ -56,7 +56,7 @@ namespace {
 
 constexpr int kWave = 64;
 enum { O_W = 0, O_N, O_D, kNumBinArrays };  // per-bin values -> epochs: weight (c r | c u), own-epoch num, denom
-enum { G_LAM = 0, G_INV, G_XA, G_P, G_BETA, G_CS, G_S, G_PW, G_INIT, kNumGather };  // per-epoch values in LDS (G_INIT: starting rates, static)
+enum { G_LAM = 0, G_INV, G_XA, G_P, G_BETA, G_CS, G_S, G_PW, kNumGather };  // per-epoch values in LDS
 
 // ----------------------------------------------------------------- lane plumbing
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -325,7 +325,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         vstat[c] = true;
       }
       lam_e[c] = p.rates_in[(size_t)rep * p.rates_stride + e];
-      if (wave == 0) s_ep[G_INIT * EPAD + e] = lam_e[c];  // kept for the epilogue's verdict
+      // the starting rates wait in the output row for the epilogue's verdict (LDS is what limits the resident
+      // workgroups of the throughput variant: 26.0 KB x 6 just fits a CU's 160 KB)
+      if (MODE == 0 && wave == 0) p.out_rates[(size_t)rep * E + e] = lam_e[c];
     }
   }
   if (tid == 0) s_ll[10] = (nzhi > nzlo) ? (double)s_kb[nzhi - 1] : -1.0;  // epoch of the oldest bin that carries data
@@ -967,15 +969,6 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #endif
   // ------------------------------------------------------------------ epilogue
   if (MODE == 0 && wave == 0) {
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      if (ep_on[c]) {
-        if (lam_e[c] != lam_e[c]) my_flags |= COLATE_FLAG_NAN;
-        p.out_rates[(size_t)rep * E + c * kWave + lane] = lam_e[c];
-      }
-    }
-  }
-  if (MODE == 0 && wave == 0) {
     // Which of the printed rates are determined by the reference's SOURCE, and which only by the last bits of the libm
     // it happens to be linked with?  The denominator of epoch e contains dt_e * integ (coal_EM.cpp:270-274, 445-449),
     // and integ carries an absolute rounding error of ~kIntegResidue per unit count: once dt_e * residue is no longer
@@ -999,7 +992,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       // the current rate (the likelihood does not depend on it), so the EM leaves it where it is -- normally at its starting
       // value, which every build prints alike.  If it has moved, rounding moved it (early iterations far from the optimum),
       // and the reference's own value is as arbitrary (tests/golden/l3_coal_modern: 42 % under 1-ulp libm noise).
-      const double init = s_ep[G_INIT * EPAD + e];
+      const double init = ep_on[c] ? p.out_rates[(size_t)rep * E + e] : 0.0;
       const bool drifted = (double)e > s_ll[10] && !(__builtin_fabs(lam_e[c] - init) <= 1e-9 * init);
       const bool resolved = !ep_on[c] || (!snapshot && !drifted &&
                             (D >= kResolvedRatio * eta || (lam_e[c] <= p.rate_floor && D < 3.0 * eta)));
@@ -1007,6 +1000,15 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       if (bad) first_bad = c * kWave + __builtin_ctzll(bad);
     }
     if (lane == 0) s_misc[3] = E - first_bad;
+  }
+  if (MODE == 0 && wave == 0) {  // (after the verdict: it reads the starting rates out of this row)
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      if (ep_on[c]) {
+        if (lam_e[c] != lam_e[c]) my_flags |= COLATE_FLAG_NAN;
+        p.out_rates[(size_t)rep * E + c * kWave + lane] = lam_e[c];
+      }
+    }
   }
   if (my_flags) atomicOr(&s_misc[2], my_flags);
   __syncthreads();
