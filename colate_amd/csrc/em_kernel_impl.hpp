@@ -230,7 +230,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   constexpr int EPAD = NCH * kWave;
   const int NBMAX = (A + kWave - 1) / kWave;  // bin groups of 64 per role
   const int AP = NBMAX * kWave;       // >= A
-  const int APZ = AP + 16;            // stride of the per-bin tiles; entries [AP, APZ) stay zero
+  const int APZ = AP + 2;             // stride of the per-bin tiles; entry AP stays zero (the "no tail" slot)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int role = wave & 1;          // 0: shared (A), 1: not shared (B)
   const int grp = wave >> 1;          // waves 2g, 2g+1 own bin group g: the live waves are 0..2*NB-1, one per SIMD
@@ -244,7 +244,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   double* s_cfail = s_nd + 4 * EPAD;                 // [2 roles][APZ] counts of bins whose normaliser failed
   double* s_cnt = s_cfail + 2 * APZ;                 // [2 roles][APZ] counts
   double* s_ll = s_cnt + 2 * APZ;                    // [8] per-wave log-likelihood partials + [2] total counts per kind + oldest data epoch
-  double* s_age = s_ll + 12;                         // [AP] age grid (throughput variant)
+  double* s_exptab = s_ll + 12;                      // [64] 2^(j/32) as hi, lo pairs for em::em_exp_t (em_math.hpp)
+  double* s_age = s_exptab + em::kExpTableDoubles;   // [AP] age grid (throughput variant)
   int* s_kb = reinterpret_cast<int*>(s_age + AP);    // [AP + 1] epoch of each bin
   int* s_fail = s_kb + AP + 1;                       // [8] per-wave "a bin failed" flags
   int* s_misc = s_fail + 8;                          // [4] nzlo, nzhi, flags
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     s_ll[tid] = 0.0;
     s_fail[tid] = 0;
   }
+  if (tid < em::kExpTableDoubles) s_exptab[tid] = em::kExpTableDevice[tid];
   __syncthreads();
   for (int t = tid; t < AP; t += blockDim.x) {
     int kb = E;  // padding: beyond every epoch
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           S_e[c] = 1.0 - cs_e[c] * 1e-3;
           omS_e[c] = cs_e[c] * 1e-3;
 #else
-          S_e[c] = em::em_exp_om(-cs_e[c], &omS_e[c]);  // omS = 1 - S_e = sum_{j<e} exp(A_ep[j])
+          S_e[c] = em::em_exp_om_t(-cs_e[c], &omS_e[c], s_exptab);  // omS = 1 - S_e = sum_{j<e} exp(A_ep[j])
 #endif
           if (ep_on[c]) {
             s_ep[G_CS * EPAD + e] = cs_e[c];
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #if COLATE_ABL_HAS(4)
             q_e[c] = 1.0 - x_e[c];
 #else
-            q_e[c] = em::em_exp(-x_e[c]);
+            q_e[c] = em::em_exp_t(-x_e[c], s_exptab);
 #endif
             if (valid) {
               p_e[c] = 1.0 - q_e[c];                                  // exp(A_ep + cs), coal_EM.cpp:119
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #if COLATE_ABL_HAS(5)
           const double qd = 1.0 - lk * da;
 #else
-          const double qd = em::em_exp(-(lk * da));  // exp(-cumsum(age) + cumsum(t_k)): same up to the rounding of cumsum
+          const double qd = em::em_exp_t(-(lk * da), s_exptab);  // exp(-cumsum(age) + cumsum(t_k)): same up to the rounding of cumsum
 #endif
 #if COLATE_ABL_HAS(8)
           const double Y = (a_b + ik) * lk;
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #if COLATE_ABL_HAS(6)
             const double u = 1.0 - lk * db;
 #else
-            const double u = em::em_exp(-(lk * db));  // exp(-cumsum(t_{k+1}) + cumsum(age)), likewise
+            const double u = em::em_exp_t(-(lk * db), s_exptab);  // exp(-cumsum(t_{k+1}) + cumsum(age)), likewise
 #endif
             const double pn = lpos ? 1.0 - u : 0.0;
             const double bn = lpos ? (a_b + ik) - (tkn + ik) * u : 0.0;
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
               }
             } else {  // last rate is 0: the mass beyond t_{k+1} is 1 - S_{E-1}/S_{k+1}
               COLATE_COLD();
-              const double Gk1 = 1.0 - em::em_exp(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + kb + 1]);
+              const double Gk1 = 1.0 - em::em_exp_t(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + kb + 1], s_exptab);
               const double SigN = pn + u * Gk1;
               if (finite_pos(SigN)) {
                 const double rr = 1.0 / SigN;
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
             double Gn = 1.0;  // mass still to coalesce after t_{e+1}, relative to survival there
             if (!absorbing) {
               COLATE_COLD();
-              Gn = 1.0 - em::em_exp(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + e + 1]);
+              Gn = 1.0 - em::em_exp_t(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + e + 1], s_exptab);
             }
             // later not-shared bins contribute dt_e each, earlier ones their tail mass
             double dns = dt_e[c] * Cn[c] + ((beta_e[c] - t_e[c] * p_e[c]) * T[c] + dt_e[c] * Gn * (q_e[c] * T[c]));
@@ -1045,8 +1047,8 @@ inline int em_rows(int E) { return E <= 16 ? 1 : (E <= 32 ? 2 : 4); }  // BASELI
 inline size_t em_lds_bytes(int E, int A) {
   const size_t EPAD = (size_t)em_chunks(E) * kWave;
   const size_t AP = (size_t)em_groups(A) * kWave;
-  const size_t APZ = AP + 16;
-  const size_t doubles = (EPAD + 1) + kNumGather * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ + 12 + AP;
+  const size_t APZ = AP + 2;
+  const size_t doubles = (EPAD + 1) + kNumGather * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ + 12 + em::kExpTableDoubles + AP;
   const size_t ints = (AP + 1) + 8 + 4 + AP;
   return doubles * sizeof(double) + ints * sizeof(int);
 }

@@ -118,6 +118,101 @@ EM_HD double em_exp_om(double x, double* one_minus) {
   return y;
 }
 
+// ---- table-driven exp(): what the EM kernel uses ---------------------------------------------------------
+// exp(x) = 2^e * 2^(j/32) * exp(r),  k = round(x * 32/ln2) = 32 e + j,  r = x - k ln2/32, |r| <= ln2/64 = 0.0108:
+// the classic table method (the one glibc's own exp() is built on, with a 32-entry table here so that it fits the
+// LDS budget of the throughput variant).  Against the series version above: a degree-7 instead of a degree-14
+// polynomial and no double-double tail -- 20 instead of 36 instructions per call on gfx950, for one LDS read.
+//   * ln2/32 is split into two 37-bit pieces, so k * piece is exact for |k| < 2^16 (|x| <= 1100) and r carries an
+//     absolute error of ~1e-18 after two FMAs: no low part of r is needed;
+//   * 2^(j/32) = th + tl to 106 bits; the result is th + (th * expm1(r) + tl), one rounding of a sum whose small
+//     term is accurate to 1e-18 relative: ~0.51 ulp, like the series version (tests/test_em_math.py measures both).
+// The table (32 x {hi, lo} = 512 bytes) lives in LDS on the device (the kernel copies kExpTable there once) and in
+// a static array on the host; tools/gen_exp_table.py regenerates the literals (mpmath, 200 bits).
+#define EM_EXP_TABLE_VALUES \
+  0x1.0000000000000p+0, 0x0.0p+0, \
+  0x1.059b0d3158574p+0, 0x1.d73e2a475b465p-55, \
+  0x1.0b5586cf9890fp+0, 0x1.8a62e4adc610bp-54, \
+  0x1.11301d0125b51p+0, -0x1.6c51039449b3ap-54, \
+  0x1.172b83c7d517bp+0, -0x1.19041b9d78a76p-55, \
+  0x1.1d4873168b9aap+0, 0x1.e016e00a2643cp-54, \
+  0x1.2387a6e756238p+0, 0x1.9b07eb6c70573p-54, \
+  0x1.29e9df51fdee1p+0, 0x1.612e8afad1255p-55, \
+  0x1.306fe0a31b715p+0, 0x1.6f46ad23182e4p-55, \
+  0x1.371a7373aa9cbp+0, -0x1.63aeabf42eae2p-54, \
+  0x1.3dea64c123422p+0, 0x1.ada0911f09ebcp-55, \
+  0x1.44e086061892dp+0, 0x1.89b7a04ef80d0p-59, \
+  0x1.4bfdad5362a27p+0, 0x1.d4397afec42e2p-56, \
+  0x1.5342b569d4f82p+0, -0x1.07abe1db13cadp-55, \
+  0x1.5ab07dd485429p+0, 0x1.6324c054647adp-54, \
+  0x1.6247eb03a5585p+0, -0x1.383c17e40b497p-54, \
+  0x1.6a09e667f3bcdp+0, -0x1.bdd3413b26456p-54, \
+  0x1.71f75e8ec5f74p+0, -0x1.16e4786887a99p-55, \
+  0x1.7a11473eb0187p+0, -0x1.41577ee04992fp-55, \
+  0x1.82589994cce13p+0, -0x1.d4c1dd41532d8p-54, \
+  0x1.8ace5422aa0dbp+0, 0x1.6e9f156864b27p-54, \
+  0x1.93737b0cdc5e5p+0, -0x1.75fc781b57ebcp-57, \
+  0x1.9c49182a3f090p+0, 0x1.c7c46b071f2bep-56, \
+  0x1.a5503b23e255dp+0, -0x1.d2f6edb8d41e1p-54, \
+  0x1.ae89f995ad3adp+0, 0x1.7a1cd345dcc81p-54, \
+  0x1.b7f76f2fb5e47p+0, -0x1.5584f7e54ac3bp-56, \
+  0x1.c199bdd85529cp+0, 0x1.11065895048ddp-55, \
+  0x1.cb720dcef9069p+0, 0x1.503cbd1e949dbp-56, \
+  0x1.d5818dcfba487p+0, 0x1.2ed02d75b3707p-55, \
+  0x1.dfc97337b9b5fp+0, -0x1.1a5cd4f184b5cp-54, \
+  0x1.ea4afa2a490dap+0, -0x1.e9c23179c2893p-54, \
+  0x1.f50765b6e4540p+0, 0x1.9d3e12dd8a18bp-54
+constexpr int kExpTableDoubles = 64;
+#if defined(__HIPCC__) || defined(__HIP__)
+static __device__ const double kExpTableDevice[kExpTableDoubles] = {EM_EXP_TABLE_VALUES};
+#endif
+static const double kExpTableHost[kExpTableDoubles] = {EM_EXP_TABLE_VALUES};
+
+struct ExpTab {
+  double th, tl, p;  // exp(xc) = 2^e (th + (th p + tl)), p = expm1(r)
+  int e;
+};
+EM_HD ExpTab em_exp_tab_parts(double xc, const double* tab) {
+  const double INVLN2N = 0x1.71547652b82fep+5;   // 32 / ln2
+  const double LN2N_HI = 0x1.62e42fefa0000p-6;   // ln2/32, first 37 bits
+  const double LN2N_MID = 0x1.cf79abc9e0000p-45; // next 37 bits (what is left is 1e-25)
+  const double SHIFT = 0x1.8p52;
+  ExpTab o;
+  const double kd = fma_(xc, INVLN2N, SHIFT);  // k = nearest integer to 32 x / ln2 (|x| <= 1100: |k| < 2^16)
+  const int ki = em_lo32(kd);
+  const double k = kd - SHIFT;
+  const double r = fma_(-k, LN2N_MID, fma_(-k, LN2N_HI, xc));  // first FMA exact, second rounds at ~1e-18
+  const int j = ki & 31;
+  o.e = ki >> 5;
+  o.th = tab[2 * j];
+  o.tl = tab[2 * j + 1];
+  // expm1(r) = r + r^2 (1/2 + r/3! + ... + r^5/7!), Estrin
+  const double r2 = r * r;
+  const double a = fma_cc(0x1.5555555555555p-3, r, 0x1.0000000000000p-1);   // 1/2! + r/3!
+  const double b = fma_cc(0x1.1111111111111p-7, r, 0x1.5555555555555p-5);   // 1/4! + r/5!
+  const double c = fma_cc(0x1.a01a01a01a01ap-13, r, 0x1.6c16c16c16c17p-10); // 1/6! + r/7!
+  const double r4 = r2 * r2;
+  const double q = fma_(c, r4, fma_(b, r2, a));
+  o.p = fma_(r2, q, r);
+  return o;
+}
+// exp(x) for x <= 709 (any value down to -inf; a NaN is not propagated, as in em_exp)
+EM_HD double em_exp_t(double x, const double* tab) {
+  const double xc = max_c(x, -1100.0);
+  const ExpTab o = em_exp_tab_parts(xc, tab);
+  return __builtin_ldexp(o.th + fma_(o.th, o.p, o.tl), o.e);
+}
+// exp(x) and 1 - exp(x) for x <= 0, the latter without cancellation near 0: with yh = 2^e th (exact) and
+// yl = 2^e (th p + tl), 1 - exp = (1 - yh) - yl, where 1 - yh is exact whenever exp(x) >= 1/2
+EM_HD double em_exp_om_t(double x, double* one_minus, const double* tab) {
+  const double xc = max_c(x, -1100.0);
+  const ExpTab o = em_exp_tab_parts(xc, tab);
+  const double yh = __builtin_ldexp(o.th, o.e);
+  const double yl = __builtin_ldexp(fma_(o.th, o.p, o.tl), o.e);
+  *one_minus = (1.0 - yh) - yl;
+  return yh + yl;
+}
+
 // 1/x for finite x > 0 within ~1 ulp (not correctly rounded): hardware seed + two Newton steps.
 // Used only where the reference has no division of its own (normalising constants).
 EM_HD double em_rcp(double x) {

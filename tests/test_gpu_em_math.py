@@ -21,7 +21,9 @@ def _host(tmp_path):
     src.write_text('#include "%s/colate_amd/csrc/em_math.hpp"\nextern "C" {\n'
                    "void t_exp(int n,const double*x,double*y){for(int i=0;i<n;i++)y[i]=em::em_exp(x[i]);}\n"
                    "void t_om(int n,const double*x,double*y,double*z){for(int i=0;i<n;i++)y[i]=em::em_exp_om(x[i],&z[i]);}\n"
-                   "void t_log(int n,const double*x,double*y){for(int i=0;i<n;i++)y[i]=em::em_log(x[i]);}\n}\n" % ROOT)
+                   "void t_log(int n,const double*x,double*y){for(int i=0;i<n;i++)y[i]=em::em_log(x[i]);}\n"
+                   "void t_exp_t(int n,const double*x,double*y){for(int i=0;i<n;i++)y[i]=em::em_exp_t(x[i],em::kExpTableHost);}\n"
+                   "void t_om_t(int n,const double*x,double*y,double*z){for(int i=0;i<n;i++)y[i]=em::em_exp_om_t(x[i],&z[i],em::kExpTableHost);}\n}\n" % ROOT)
     so = tmp_path / "libh.so"
     subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(so), str(src)])
     return ctypes.CDLL(str(so))
@@ -40,7 +42,7 @@ def test_device_math_equals_host_build(tmp_path):
     (tmp_path / "in.bin").write_bytes(np.concatenate([x, aux]).tobytes())
     exe = os.path.join(ROOT, "colate_amd", "bin", "em_math_device")
     subprocess.check_call([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
-    out = np.frombuffer((tmp_path / "out.bin").read_bytes(), dtype=np.float64).reshape(7, n)
+    out = np.frombuffer((tmp_path / "out.bin").read_bytes(), dtype=np.float64).reshape(10, n)
     h = _host(tmp_path)
     y = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
     P = lambda a: a.ctypes.data_as(dp)  # noqa: E731
@@ -51,6 +53,11 @@ def test_device_math_equals_host_build(tmp_path):
     assert np.array_equal(out[0], y[0]), "em_exp differs between gfx950 and the host build"
     assert np.array_equal(out[1], y[1]) and np.array_equal(out[2], y[2]), "em_exp_om differs"
     assert np.array_equal(out[3], y[3]), "em_log differs"
+    yt, yo, zo = np.zeros(n), np.zeros(n), np.zeros(n)
+    h.t_exp_t(n, P(x), P(yt))
+    h.t_om_t(n, P(x), P(yo), P(zo))
+    assert np.array_equal(out[7], yt), "em_exp_t (the table-driven exp the kernel uses) differs between gfx950 and the host build"
+    assert np.array_equal(out[8], yo) and np.array_equal(out[9], zo), "em_exp_om_t differs"
     pos = a > 1e-290
     inv = 1.0 / a[pos]
     assert np.array_equal(out[6][pos], inv), "device IEEE division differs from the host's"
