@@ -192,13 +192,14 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput) {
 #else
   (void)erows;
   if (mode != 0) return 0;
-  // measured on MI355X, kernel ms for pads 0..7, final loop code of round 2 (gpurun_out/r02l/ab_tx.txt -> profiles/r02_placement.txt):
+  // measured on MI355X, kernel ms for pads 0..7, final loop code of round 2 (gpurun_out/r02m/ab_lk.txt, r02l/ab_tx.txt ->
+  // profiles/r02_placement.txt):
 #ifdef COLATE_EM_ILP_BUILD
   (void)tput;
-  // latency variant, max-ilp build: E=23 B=100 1.400 1.396 1.390 1.407 1.387 1.404 1.402 1.394; E=122 B=100 2.179 2.181 2.188 2.192 2.178 2.151 2.160 2.203
-  return nch == 1 ? 4 : 5;
+  // latency variant, max-ilp build: E=23 B=100 1.390 1.356 1.379 1.431 1.423 1.397 1.416 1.395; E=122 B=100 2.172 2.151 2.205 2.178 2.167 2.203 2.148 2.147
+  return nch == 1 ? 1 : 7;
 #else
-  if (!tput) return 4;       // latency variant, default build: E=23 B=400 1.676 1.670 1.657 1.657 1.648 1.663 1.660 1.662
+  if (!tput) return 6;       // latency variant, default build: E=23 B=400 1.646 1.662 1.651 1.649 1.689 1.668 1.635 1.645
   return nch == 1 ? 1 : 0;   // throughput variant: E=23 B=4096 7.85 7.74 7.77 7.85 7.82 7.83 7.83 7.83
 #endif
 #endif
@@ -552,6 +553,23 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         }
       }
     }
+    // The rate of this lane's own bin's epoch, lambda_k, is known to every wave before barrier 1 (each wave runs the
+    // M-step itself): fetching it from the wave's own registers (ds_bpermute, issued here so that its latency falls into
+    // the wait the barrier needs anyway) lets the bin's exp(-lambda_k (age - t_k)) start right behind the barrier instead
+    // of behind the LDS gather of the other per-epoch values.  Same value, so nothing changes but the time.
+    double lk_pre = 0.0;
+#ifndef COLATE_NO_LK_PREFETCH
+    if (!TPUT) {
+      const int kq = bs0.kb < E ? bs0.kb : 0;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        const int lo = __builtin_amdgcn_ds_bpermute((kq & 63) << 2, __double2loint(lam_e[c]));
+        const int hi = __builtin_amdgcn_ds_bpermute((kq & 63) << 2, __double2hiint(lam_e[c]));
+        if (NCH == 1 || (kq >> 6) == c) lk_pre = __hiloint2double(hi, lo);
+      }
+      asm volatile("" : "+v"(lk_pre));  // (keeps the fetch on this side of the barrier)
+    }
+#endif
     COLATE_STAMP(9)
     __syncthreads();  // ---- barrier 1: epoch values visible
     COLATE_STAMP(0)
@@ -560,7 +578,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     const double lam_last = s_ep[G_LAM * EPAD + E - 1];
     const bool absorbing = lam_last > 0;
     // ============================================================ P2: bin terms (own bins, own role)
-    auto bin_terms = [&](const BinStat& bs) {
+    auto bin_terms = [&](const BinStat& bs, const double lk_own, const bool have_lk) {
       const double a_b = bs.a_b, cnt = bs.cnt, tk = bs.tk, tkn = bs.tkn, dtk = bs.dtk, da = bs.da, db = bs.db;
       const double f1 = bs.f1, f2 = bs.f2, f4 = bs.f4, f8 = bs.f8;
       const int kb = bs.kb, pos = bs.pos;
@@ -569,7 +587,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       double o_w = 0, o_N = 0, o_D = 0, llp = 0.0;
       bool fail = false;
       if (live && !COLATE_ABL_HAS(12)) {
-        const double lk = s_ep[G_LAM * EPAD + kb], ik = s_ep[G_INV * EPAD + kb];
+        const double lk = have_lk ? lk_own : s_ep[G_LAM * EPAD + kb], ik = s_ep[G_INV * EPAD + kb];
         const bool lpos = lk > 0;
         // -cumsum(age) at the merged grid (coal_EM.cpp:178-181): only the log-likelihood needs it
         auto neg_cs_age = [&]() {
@@ -720,10 +738,14 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         b.live = inr && b.cnt > 0;
         b.last_bin = (b.kb == E - 1);
         b.is_tail = fl & BF_TAIL;
-        bin_terms(b);
+        bin_terms(b, 0.0, false);
       }
     } else {
-      bin_terms(bs0);
+#ifndef COLATE_NO_LK_PREFETCH
+      bin_terms(bs0, lk_pre, true);
+#else
+      bin_terms(bs0, 0.0, false);
+#endif
     }
     COLATE_STAMP(2)
     __syncthreads();  // ---- barrier 2: per-bin tails visible
