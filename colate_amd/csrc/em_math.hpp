@@ -197,7 +197,12 @@ EM_HD ExpTab em_exp_tab_parts(double xc, const double* tab) {
   return o;
 }
 // exp(x) for x <= 709 (any value down to -inf; a NaN is not propagated, as in em_exp)
+// (-DCOLATE_EXP_SERIES: experiments only -- the kernel then evaluates the series version through the same calls)
 EM_HD double em_exp_t(double x, const double* tab) {
+#ifdef COLATE_EXP_SERIES
+  (void)tab;
+  return em_exp(x);
+#endif
   const double xc = max_c(x, -1100.0);
   const ExpTab o = em_exp_tab_parts(xc, tab);
   return __builtin_ldexp(o.th + fma_(o.th, o.p, o.tl), o.e);
@@ -205,6 +210,10 @@ EM_HD double em_exp_t(double x, const double* tab) {
 // exp(x) and 1 - exp(x) for x <= 0, the latter without cancellation near 0: with yh = 2^e th (exact) and
 // yl = 2^e (th p + tl), 1 - exp = (1 - yh) - yl, where 1 - yh is exact whenever exp(x) >= 1/2
 EM_HD double em_exp_om_t(double x, double* one_minus, const double* tab) {
+#ifdef COLATE_EXP_SERIES
+  (void)tab;
+  return em_exp_om(x, one_minus);
+#endif
   const double xc = max_c(x, -1100.0);
   const ExpTab o = em_exp_tab_parts(xc, tab);
   const double yh = __builtin_ldexp(o.th, o.e);
