@@ -116,7 +116,24 @@ def cpu_baseline(grid, csh, cns, epochs, gpu_rates, gpu_iters, bins=BINS):
                     ref_tok = lines[2 + b].split()[2:]
                     gpu_tok = ["%g" % x for x in gpu_rates[b]]
                     diff_per_epoch += np.array([a != c for a, c in zip(ref_tok, gpu_tok)], dtype=np.int64)
+                # ... and replicate-parallel over the host cores this process may use: P copies
+                # of the single-threaded reference binary side by side, `per` replicates each
+                P = max(1, min(len(os.sched_getaffinity(0)), 32))
+                per = max(4, S // 4)
+                for k in range(P):
+                    os.makedirs(os.path.join(d, f"p{k}"))
+                    idx = [(k * per + i) % csh.shape[0] for i in range(per)]
+                    write_colate_mat(os.path.join(d, f"p{k}", "OUT.colate_mat"), grid, csh[idx], cns[idx])
+                cmd_p = [ref_bin, "--mode", "mut", "--mut", "dummy", "--bins", bins, "--num_bootstraps", str(per), "-o", "OUT"]
+                t1 = time.perf_counter()
+                procs = [subprocess.Popen(cmd_p, cwd=os.path.join(d, f"p{k}"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                         for k in range(P)]
+                ok_all = all(q.wait() == 0 for q in procs)
+                dt_all = time.perf_counter() - t1
+                all_cores = {"value": P * per / dt_all, "unit": "replicates/s", "cores": P,
+                             "sample": f"{P} concurrent copies of the reference binary x {per} replicates, {dt_all:.1f} s wall"} if ok_all else None
                 return {
+                    "all_cores": all_cores,
                     "value": S / dt, "unit": "replicates/s", "cores": 1, "kind": "reference",
                     "sample": f"{S} of the benchmark's replicates through the reference binary (.colate_mat hook), "
                               f"{dt:.1f} s wall incl. its start-up",
