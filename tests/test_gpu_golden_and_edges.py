@@ -302,8 +302,10 @@ def test_throughput_variant_is_bit_identical(ca, monkeypatch):
     from colate_amd import workloads
 
     grid = ol.age_grid()
-    for bins, nrep in (("3,7,0.2", 12), ("2,7.95,0.05", 3), ("3,7,0.3", 3)):
-        ep, _ = ol.epochs_from_bins(bins)
+    cases = [(ol.epochs_from_bins(bins)[0], nrep) for bins, nrep in (("3,7,0.2", 12), ("2,7.95,0.05", 3), ("3,7,0.3", 3))]
+    # both sides of the limits of the 1-, 2- and 4-row instantiations (16 / 32 epochs)
+    cases += [(np.concatenate([[0.0], np.geomspace(30, 3e5, n - 2), [4e6]]), 3) for n in (16, 31, 32, 33)]
+    for ep, nrep in cases:
         csh, cns = workloads.bootstrap_tables(grid, nrep, nb=9, scale=1.0)
         csh[0, :] = 0.0          # a replicate without shared counts
         cns[1, 60:] = 0.0        # one whose data stop early (one bin group)
