@@ -444,9 +444,11 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   (void)nwave_live;
 
   int my_flags = 0;
-  unsigned long long ever_copied[NCH];  // bit l: epoch l of the chunk had num == 0 ("copy the previous rate", coal.cpp:3779-3788) in some iteration
+  // bit l: the numerator of epoch l of the chunk was below kTinyNum (0 included) / was not 0 in some iteration
+  constexpr double kTinyNum = 1e-280;
+  unsigned long long ever_tiny[NCH], ever_nonzero[NCH];
 #pragma unroll
-  for (int c = 0; c < NCH; c++) ever_copied[c] = 0;
+  for (int c = 0; c < NCH; c++) ever_tiny[c] = ever_nonzero[c] = 0;
   bool wrote_fail = false, flag_set = false;
   const double thr = 1.0 - p.rel_tol;
   double ll = -__builtin_inf(), prev_ll = -__builtin_inf();  // coal.cpp:3685
@@ -934,7 +936,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         }
         keep[c] = __ballot(ep_on[c] && !copy);
         const unsigned long long cp = __ballot(ep_on[c] && copy);
-        ever_copied[c] |= cp;  // (scalar; for the epilogue's verdict)
+        // (scalar masks for the epilogue's verdict: was the numerator ever at the edge of underflow / ever not zero?)
+        ever_tiny[c] |= __ballot(ep_on[c] && !(N_e[c] >= kTinyNum));
+        ever_nonzero[c] |= __ballot(ep_on[c] && N_e[c] != 0.0);
         if (cp && (lower_keep || (cp & (cp + 1ull)))) simple = false;
         if (keep[c]) lower_keep = true;
       }
@@ -1008,10 +1012,14 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       const double D = s_nd[1 * EPAD + e] + s_nd[3 * EPAD + e];  // denominators of the last E-step
       const double Nfin = s_nd[0 * EPAD + e] + s_nd[2 * EPAD + e];
       const double eta = dt_e[c] * (kIntegResidue * (s_ll[8] + s_ll[9]));  // dt_e * residue of ALL bins (both kinds); 0 in the last epoch and beyond E
-      // A numerator that was exactly 0 in some iterations (underflow: the rate copied its neighbour's, coal.cpp:3779-3788)
-      // and is not at the end leaves the rate at whatever the neighbour was when the underflow ended -- a snapshot that
-      // depends on the last bits of exp(); an epoch that copies to the end, or never did, is fine.
-      const bool snapshot = ((ever_copied[c] >> lane) & 1ull) && Nfin != 0.0;
+      // A numerator of exactly 0 makes the rate copy its neighbour's (coal.cpp:3779-3788); when it is 0 in some
+      // iterations and not in others (underflow: survival below ~1e-308) the rate ends as a snapshot of the neighbour at
+      // the moment the underflow ended -- or never copies at all, depending on where exactly an implementation's products
+      // reach zero (the reference's exp(A_e - Z_b) per bin, the kernel's W_e RS_e and q_e T_e chains).  So an epoch whose
+      // numerator was ever within a factor 1e-280 of that edge while not being a structural zero (0 in every iteration,
+      // like epoch 0) is not reproducible.
+      (void)Nfin;
+      const bool snapshot = ((ever_tiny[c] >> lane) & 1ull) && ((ever_nonzero[c] >> lane) & 1ull);
       // An epoch that starts after the oldest bin with data: every contribution to its statistics has num/denom equal to
       // the current rate (the likelihood does not depend on it), so the EM leaves it where it is -- normally at its starting
       // value, which every build prints alike.  If it has moved, rounding moved it (early iterations far from the optimum),
