@@ -449,6 +449,16 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   unsigned long long ever_tiny[NCH], ever_nonzero[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; c++) ever_tiny[c] = ever_nonzero[c] = 0;
+  // any epoch (up to the oldest data) whose rate was, in some iteration, a quotient with a denominator below kNoisyRatio residues (and neither a
+  // copy nor clamped to the floor): the reference's own trajectory is then rounding noise of >= 1e-4 per iteration there
+  // (its integ residue, see kResolvedRatio) -- harmless for epochs that converge to a fixed point, decisive for the
+  // flat epochs behind all data, whose final value records the history (epilogue)
+  constexpr double kNoisyRatio = 1.0e6;
+  unsigned long long ever_noisy = 0;
+  double noisy_thr[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; c++)  // (only epochs up to the oldest bin with data: the flat ones behind it do not move at all)
+    noisy_thr[c] = (double)(c * kWave + lane) <= s_ll[10] ? kNoisyRatio * (dt_e[c] * (kIntegResidue * (s_ll[8] + s_ll[9]))) : 0.0;
   bool wrote_fail = false, flag_set = false;
   const double thr = 1.0 - p.rel_tol;
   double ll = -__builtin_inf(), prev_ll = -__builtin_inf();  // coal.cpp:3685
@@ -939,6 +949,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         // (scalar masks for the epilogue's verdict: was the numerator ever at the edge of underflow / ever not zero?)
         ever_tiny[c] |= __ballot(ep_on[c] && !(N_e[c] >= kTinyNum));
         ever_nonzero[c] |= __ballot(ep_on[c] && N_e[c] != 0.0);
+        ever_noisy |= __ballot(ep_on[c] && !copy && D_e[c] < noisy_thr[c] && cand[c] > p.rate_floor);
         if (cp && (lower_keep || (cp & (cp + 1ull)))) simple = false;
         if (keep[c]) lower_keep = true;
       }
@@ -1026,7 +1037,13 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       // and the reference's own value is as arbitrary (tests/golden/l3_coal_modern: 42 % under 1-ulp libm noise).
       const double init = ep_on[c] ? p.out_rates[(size_t)rep * E + e] : 0.0;
       const bool drifted = (double)e > s_ll[10] && !(__builtin_fabs(lam_e[c] - init) <= 1e-9 * init);
-      const bool resolved = !ep_on[c] || (!snapshot && !drifted &&
+      // ... and even unmoved it is a record of the path: had the numerator been 0 in one iteration it would have copied
+      // its neighbour.  Whether that happens in the reference depends on how high the rates of the epochs before it went
+      // on the way, and where one of those was ever a quotient of rounding residue (ever_noisy) the reference's path is its
+      // own (measured: sparse tables, the last epoch with data overshoots x4 on the reference, its survival underflows and
+      // the flat epoch behind it ends as a copy, while the exact sums never come near; profiles/parity/sweep2_sparse_*).
+      const bool path_dependent = (double)e > s_ll[10] && ever_noisy != 0;
+      const bool resolved = !ep_on[c] || (!snapshot && !drifted && !path_dependent &&
                             (D >= kResolvedRatio * eta || (lam_e[c] <= p.rate_floor && D < 3.0 * eta)));
       const unsigned long long bad = __ballot(!resolved);
       if (bad) first_bad = c * kWave + __builtin_ctzll(bad);
