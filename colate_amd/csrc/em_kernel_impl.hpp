@@ -192,15 +192,15 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput) {
 #else
   (void)erows;
   if (mode != 0) return 0;
-  // measured on MI355X, kernel ms for pads 0..7, final loop code of round 2 (gpurun_out/r02m/ab_lk.txt, r02l/ab_tx.txt ->
+  // measured on MI355X, kernel ms for pads 0..7, final loop code of round 2 (gpurun_out/r02g/padsweep.txt ->
   // profiles/r02_placement.txt):
 #ifdef COLATE_EM_ILP_BUILD
-  (void)tput;
-  // latency variant, max-ilp build: E=23 B=100 1.390 1.356 1.379 1.431 1.423 1.397 1.416 1.395; E=122 B=100 2.172 2.151 2.205 2.178 2.167 2.203 2.148 2.147
-  return nch == 1 ? 1 : 7;
+  (void)tput, (void)nch;
+  // latency variant, max-ilp build: E=23 B=100 1.397 1.415 1.425 1.393 1.366 1.381 1.364 1.406; E=122 B=100 2.178 2.168 2.184 2.208 2.245 2.185 2.157 2.179
+  return 6;
 #else
-  if (!tput) return 6;       // latency variant, default build: E=23 B=400 1.646 1.662 1.651 1.649 1.689 1.668 1.635 1.645
-  return nch == 1 ? 1 : 0;   // throughput variant: E=23 B=4096 7.85 7.74 7.77 7.85 7.82 7.83 7.83 7.83
+  if (!tput) return 6;       // latency variant, default build: E=23 B=400 1.649 1.667 1.643 1.635 1.636 1.656 1.621 1.637
+  return nch == 1 ? 1 : 0;   // throughput variant: E=23 B=4096 7.92 7.96 7.95 7.93 7.95 7.93 7.94 7.91 (flat)
 #endif
 #endif
 }
@@ -438,6 +438,11 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   __syncthreads();
   if (!TPUT && grp >= NB) return;  // waves without bins retire; later barriers count the remaining waves only
   const bool leader = (grp == 0);
+  // The wave that keeps the verdict's history masks in the M-step and writes the verdict and the rates at the end: a
+  // wave of the second bin group when there is one (it sits out P1 and P3, so this is off the critical chain; on the
+  // leaders it cost 3.5 % at E=23 and 7 % at E=122, profiles/r02_placement.txt), else wave 0.
+  const int verdict_wave = (!TPUT && NB >= 2) ? 2 : 0;
+  const bool tracker = (wave == verdict_wave);
   constexpr int erows = EROWS;  // 16-lane rows that hold epochs: a compile-time constant (skipping the cross-row
                                 // scan steps behind run-time uniform branches measured slower)
   const int nwave_live = 2 * NB;
@@ -946,12 +951,16 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         }
         keep[c] = __ballot(ep_on[c] && !copy);
         const unsigned long long cp = __ballot(ep_on[c] && copy);
-        // (scalar masks for the epilogue's verdict: was the numerator ever at the edge of underflow / ever not zero?)
-        ever_tiny[c] |= __ballot(ep_on[c] && !(N_e[c] >= kTinyNum));
-        ever_nonzero[c] |= __ballot(ep_on[c] && N_e[c] != 0.0);
-        ever_noisy |= __ballot(ep_on[c] && !copy && D_e[c] < noisy_thr[c] && cand[c] > p.rate_floor);
         if (cp && (lower_keep || (cp & (cp + 1ull)))) simple = false;
         if (keep[c]) lower_keep = true;
+      }
+      if (tracker) {  // scalar masks for the epilogue's verdict, kept by a wave that has time for it
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+          ever_tiny[c] |= __ballot(ep_on[c] && !(N_e[c] >= kTinyNum));
+          ever_nonzero[c] |= __ballot(ep_on[c] && N_e[c] != 0.0);
+          ever_noisy |= __ballot(ep_on[c] && N_e[c] != 0.0 && D_e[c] < noisy_thr[c] && cand[c] > p.rate_floor);
+        }
       }
       if (simple) {
 #pragma unroll
@@ -1007,7 +1016,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   }
 #endif
   // ------------------------------------------------------------------ epilogue
-  if (MODE == 0 && wave == 0) {
+  if (MODE == 0 && tracker) {
     // Which of the printed rates are determined by the reference's SOURCE, and which only by the last bits of the libm
     // it happens to be linked with?  The denominator of epoch e contains dt_e * integ (coal_EM.cpp:270-274, 445-449),
     // and integ carries an absolute rounding error of ~kIntegResidue per unit count: once dt_e * residue is no longer
@@ -1050,7 +1059,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     }
     if (lane == 0) s_misc[3] = E - first_bad;
   }
-  if (MODE == 0 && wave == 0) {  // (after the verdict: it reads the starting rates out of this row)
+  if (MODE == 0 && tracker) {  // (after the verdict: it reads the starting rates out of this row)
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       if (ep_on[c]) {
