@@ -48,6 +48,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "em_kernels.h"
 #include "em_math.hpp"
@@ -487,18 +488,22 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     COLATE_PAD_CASE(4) COLATE_PAD_CASE(5) COLATE_PAD_CASE(6) COLATE_PAD_CASE(7)
 #undef COLATE_PAD_CASE
   }
-  for (iter = 0; iter < max_iter; iter++) {
+  auto iteration = [&](auto role_c, auto leader_c, auto ll_c) __attribute__((always_inline)) -> bool {
     COLATE_STAMP(7)
-    const bool need_ll = (MODE == 1) || (iter >= p.min_iter) || (iter == max_iter - 1);
-    // ============================================================ P1: epoch values (role leaders)
+    // (compile-time role / leadership / "no log-likelihood needed" in the steady-state loops below; -1 = run-time value)
+    constexpr int kRole = decltype(role_c)::value, kLeader = decltype(leader_c)::value, kNeedLL = decltype(ll_c)::value;
+    const int ROLE = kRole < 0 ? role : kRole;
+    const bool LEADER = kLeader < 0 ? leader : (kLeader != 0);
+    const bool need_ll = kNeedLL < 0 ? ((MODE == 1) || (iter >= p.min_iter) || (iter == max_iter - 1)) : (kNeedLL != 0);
+    // ============================================================ P1: epoch values (ROLE leaders)
     double q_e[NCH], p_e[NCH], beta_e[NCH], S_e[NCH], omS_e[NCH], cs_e[NCH], csn_e[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) q_e[c] = p_e[c] = beta_e[c] = S_e[c] = omS_e[c] = cs_e[c] = csn_e[c] = 0.0;
-    if (leader && !COLATE_ABL_HAS(15)) {
+    if (LEADER && !COLATE_ABL_HAS(15)) {
       double x_e[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; c++) x_e[c] = lam_e[c] * dt_e[c];
-      if (role == 0) {
+      if (ROLE == 0) {
         // cs_e = sum_{j<e} lambda_j dt_j (coal_EM.cpp:100-103), as a wave scan
         double carry = 0.0;
 #pragma unroll
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         }
       }
       COLATE_STAMP(8)
-      if (role == 0) {
+      if (ROLE == 0) {
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           const int e = c * kWave + lane;
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           const bool valid = vstat[c] && (lam_e[c] > 0);
           if (e < E - 1) {
             // exp(-cumsum[i+1] + cumsum[i]) of coal_EM.cpp:120, taken as exp(-lambda_e dt_e): the two arguments
-            // differ by the rounding of cumsum (<= ulp(cs)/2), and role B then needs no scan at all
+            // differ by the rounding of cumsum (<= ulp(cs)/2), and ROLE B then needs no scan at all
 #if COLATE_ABL_HAS(4)
             q_e[c] = 1.0 - x_e[c];
 #else
@@ -594,13 +599,13 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     // for bins inside the last epoch (coal_EM.cpp:351)
     const double lam_last = s_ep[G_LAM * EPAD + E - 1];
     const bool absorbing = lam_last > 0;
-    // ============================================================ P2: bin terms (own bins, own role)
+    // ============================================================ P2: bin terms (own bins, own ROLE)
     auto bin_terms = [&](const BinStat& bs, const double lk_own, const bool have_lk) {
       const double a_b = bs.a_b, cnt = bs.cnt, tk = bs.tk, tkn = bs.tkn, dtk = bs.dtk, da = bs.da, db = bs.db;
       const double f1 = bs.f1, f2 = bs.f2, f4 = bs.f4, f8 = bs.f8;
       const int kb = bs.kb, pos = bs.pos;
       const bool live = bs.live, last_bin = bs.last_bin, is_tail = bs.is_tail;
-      const int wslot = 2 * (pos >> 6) + role;  // entry of this (bin group, role) in s_fail / s_ll: the latency variant's wave
+      const int wslot = 2 * (pos >> 6) + ROLE;  // entry of this (bin group, ROLE) in s_fail / s_ll: the latency variant's wave
       double o_w = 0, o_N = 0, o_D = 0, llp = 0.0;
       bool fail = false;
       if (live && !COLATE_ABL_HAS(12)) {
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           const double ck1 = ck + lk * da;
           return -(ck1 + lk * (a_b - a_b));  // (second copy of `age` in the merged grid)
         };
-        if (role == 0) {  // ---- EM_shared, coal_EM.cpp:198-210, 263-287
+        if (ROLE == 0) {  // ---- EM_shared, coal_EM.cpp:198-210, 263-287
           const double Sk = s_ep[G_S * EPAD + kb], Xak = s_ep[G_XA * EPAD + kb], PWk = s_ep[G_PW * EPAD + kb];
 #if COLATE_ABL_HAS(5)
           const double qd = 1.0 - lk * da;
@@ -695,14 +700,14 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       COLATE_STAMP(1)
       // bins whose normaliser failed (coal_EM.cpp:288-292, 461-465) drop out of the static counts
       if (TPUT) {  // (a wave serves several groups: publish every time)
-        s_cfail[role * APZ + pos] = fail ? cnt : 0.0;
+        s_cfail[ROLE * APZ + pos] = fail ? cnt : 0.0;
         const bool any_fail = __any(fail);
         if (lane == 0) s_fail[wslot] = any_fail ? 1 : 0;
       } else {
         const bool any_fail = __any(fail);
         if (fail || wrote_fail) {  // publish, or clear what this lane published last time
           COLATE_COLD();
-          s_cfail[role * APZ + pos] = fail ? cnt : 0.0;
+          s_cfail[ROLE * APZ + pos] = fail ? cnt : 0.0;
         }
         wrote_fail = fail;
         if (any_fail != flag_set) {  // (uniform) publish the per-wave flag only when it changes
@@ -735,14 +740,14 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       }
     };
     if (TPUT) {
-      for (int g = 0; g < NB; g++) {  // this role's bin groups, one after the other
+      for (int g = 0; g < NB; g++) {  // this ROLE's bin groups, one after the other
         const int gpos = g * kWave + lane, fl = s_bflags[gpos], gbin = nzlo + gpos;
         const bool inr = fl & BF_INRANGE;
         BinStat b;
         b.kb = inr ? (fl >> BF_KB_SHIFT) : 0;
         b.pos = gpos;
         b.a_b = inr ? s_age[gbin] : 0.0;
-        b.cnt = inr ? s_cnt[role * APZ + gbin] : 0.0;
+        b.cnt = inr ? s_cnt[ROLE * APZ + gbin] : 0.0;
         b.tk = s_t[b.kb];
         b.tkn = (b.kb < E - 1) ? s_t[b.kb + 1] : 0.0;
         b.dtk = (b.kb < E - 1) ? b.tkn - b.tk : 0.0;
@@ -772,11 +777,11 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       asm volatile(".p2align 5\n\t.rept 4\n\ts_nop 0\n\t.endr");
     }
     COLATE_STAMP(3)
-    // ============================================================ P3: per-epoch sums (role leaders)
-    if (leader && !COLATE_ABL_HAS(13)) {
-      // did a bin of this role fail this iteration? (entries of retired waves stay 0; loaded with the
+    // ============================================================ P3: per-epoch sums (ROLE leaders)
+    if (LEADER && !COLATE_ABL_HAS(13)) {
+      // did a bin of this ROLE fail this iteration? (entries of retired waves stay 0; loaded with the
       // tails: one LDS wait; fixed count -- a runtime-bounded loop here compiles to a vectorised monster)
-      const int anyf = s_fail[role] | s_fail[2 + role] | s_fail[4 + role] | s_fail[6 + role];
+      const int anyf = s_fail[ROLE] | s_fail[2 + ROLE] | s_fail[4 + ROLE] | s_fail[6 + ROLE];
       double w[NCH], oN[NCH], oD[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
@@ -787,7 +792,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         const double n0 = out_mine[O_N * APZ + slot0[c]], n1 = out_mine[O_N * APZ + slot1[c]], n2 = out_mine[O_N * APZ + slot2[c]];
         const double d0 = out_mine[O_D * APZ + slot0[c]], d1 = out_mine[O_D * APZ + slot1[c]], d2 = out_mine[O_D * APZ + slot2[c]];
 #endif
-        if (role == 0) {  // the shared leader also needs the not-shared leader's p_e, beta_e
+        if (ROLE == 0) {  // the shared LEADER also needs the not-shared LEADER's p_e, beta_e
           p_e[c] = s_ep[G_P * EPAD + c * kWave + lane];
           beta_e[c] = s_ep[G_BETA * EPAD + c * kWave + lane];
         }
@@ -804,7 +809,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         }
       }
       COLATE_STAMP(10)
-      // counts of this role's bins in LATER epochs, minus those whose normaliser failed this iteration
+      // counts of this ROLE's bins in LATER epochs, minus those whose normaliser failed this iteration
       double Cn[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; c++) Cn[c] = C0[c];
@@ -815,14 +820,14 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           for (int c = 0; c < NCH; c++) {
             double fs = 0.0;
             for (int q = seg_hi[c] > 0 ? seg_hi[c] : 0; ep_on[c] && q < nzhi - nzlo; q++) {
-              if (s_kb[nzlo + q] > c * kWave + lane) fs += s_cfail[role * APZ + q];
+              if (s_kb[nzlo + q] > c * kWave + lane) fs += s_cfail[ROLE * APZ + q];
             }
             Cn[c] -= fs;
           }
         }
       }
       double Npart[NCH], Dpart[NCH];
-      if (role == 0) {
+      if (ROLE == 0) {
         // RS = sum c r over the shared bins of LATER epochs (suffix sums over epochs)
         double RSn[NCH];
         double cR = 0.0;
@@ -896,8 +901,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         if (ep_on[c]) {
-          s_nd[(role * 2 + 0) * EPAD + c * kWave + lane] = Npart[c];
-          s_nd[(role * 2 + 1) * EPAD + c * kWave + lane] = Dpart[c];
+          s_nd[(ROLE * 2 + 0) * EPAD + c * kWave + lane] = Npart[c];
+          s_nd[(ROLE * 2 + 1) * EPAD + c * kWave + lane] = Dpart[c];
         }
       }
     }
@@ -929,7 +934,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           }
         }
       }
-      break;
+      return true;
     }
     // ---- M-step, coal.cpp:3777-3804
     if (!COLATE_ABL_HAS(14)) {
@@ -954,7 +959,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         if (cp && (lower_keep || (cp & (cp + 1ull)))) simple = false;
         if (keep[c]) lower_keep = true;
       }
-      if (tracker) {  // scalar masks for the epilogue's verdict, kept by a wave that has time for it
+      if (kRole != 1 && tracker) {  // scalar masks for the epilogue's verdict, kept by a wave that has time for it
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           ever_tiny[c] |= __ballot(ep_on[c] && !(N_e[c] >= kTinyNum));
@@ -990,12 +995,41 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     COLATE_STAMP(5)
     // stop rule, coal.cpp:3822 (evaluated after the update); uniform across the workgroup
     bool stop = false;
-    if (iter > p.min_iter) {
+    if (kNeedLL != 0 && iter > p.min_iter) {  // (never in the steady-state loops)
       COLATE_COLD();
       stop = (ll / prev_ll > thr);
     }
     prev_ll = ll;
-    if (stop) break;
+    return stop;
+  };
+  // Steady state: the iterations before min_iter need neither the log-likelihood nor the stop test, and a wave's role and
+  // leadership never change -- so each kind of wave runs them in a loop of its own, compiled for exactly that kind: no
+  // wave-uniform branch on role / leader / need_ll is left in it.  A taken branch costs a lone wave ~20 cycles and a
+  // not-taken one ~8 (csrc/tools/ubench_branch.hip, profiles/r02/ubench_branch.txt), against ~5 for an FP64 instruction.
+  // The waves of a workgroup run different loops but the same sequence of barriers.  The general loop below takes over
+  // from min_iter on (and is all there is for MODE 1).
+  if (MODE == 0) {
+    int n_steady = p.min_iter < max_iter - 1 ? p.min_iter : max_iter - 1;
+    if (n_steady < 0) n_steady = 0;
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    if (role == 0) {
+      if (leader) {
+        for (; iter < n_steady; iter++) iteration(C0{}, C1{}, C0{});
+      } else {
+        for (; iter < n_steady; iter++) iteration(C0{}, C0{}, C0{});
+      }
+    } else {
+      if (leader) {
+        for (; iter < n_steady; iter++) iteration(C1{}, C1{}, C0{});
+      } else {
+        for (; iter < n_steady; iter++) iteration(C1{}, C0{}, C0{});
+      }
+    }
+  }
+  for (; iter < max_iter; iter++) {
+    using CR = std::integral_constant<int, -1>;
+    if (iteration(CR{}, CR{}, CR{})) break;
   }
 
 #ifdef COLATE_EM_STAMPS
