@@ -233,7 +233,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   const int NBMAX = (A + kWave - 1) / kWave;  // bin groups of 64 per role
   const int AP = NBMAX * kWave;       // >= A
   const int APZ = AP + 2;             // stride of the per-bin tiles; entry AP stays zero (the "no tail" slot)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (a scalar: branches on role / group / wave are s_cbranch_scc)
   const int role = wave & 1;          // 0: shared (A), 1: not shared (B)
   const int grp = wave >> 1;          // waves 2g, 2g+1 own bin group g: the live waves are 0..2*NB-1, one per SIMD
   const int rep = blockIdx.x;
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       dtk = tkn - tk;
     }
     da = a_b - tk;
-    db = tkn - a_b;
+    db = (kb < E - 1) ? tkn - a_b : 0.0;  // (bins in the last epoch: no end of epoch)
   }
   const bool live = in_range && cnt > 0;
   const bool last_bin = (kb == E - 1);
@@ -436,6 +437,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       row_hi[c] = r1;
     }
   }
+  bool more_rows[NCH];  // (wave-uniform) some epoch of the chunk spans more than three 16-lane rows
+#pragma unroll
+  for (int c = 0; c < NCH; c++) more_rows[c] = __any(row_x[c] <= row_hi[c]);
   __syncthreads();
   if (!TPUT && grp >= NB) return;  // waves without bins retire; later barriers count the remaining waves only
   const bool leader = (grp == 0);
@@ -545,22 +549,18 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           const double inv = 1.0 / lam_e[c];
 #endif
           const bool valid = vstat[c] && (lam_e[c] > 0);
-          if (e < E - 1) {
-            // exp(-cumsum[i+1] + cumsum[i]) of coal_EM.cpp:120, taken as exp(-lambda_e dt_e): the two arguments
-            // differ by the rounding of cumsum (<= ulp(cs)/2), and ROLE B then needs no scan at all
+          // exp(-cumsum[i+1] + cumsum[i]) of coal_EM.cpp:120, taken as exp(-lambda_e dt_e): the two arguments
+          // differ by the rounding of cumsum (<= ulp(cs)/2), and role B then needs no scan at all.  No branch on the last
+          // epoch (coal_EM.cpp:136-141: p = 1, beta = t + 1/lambda): with q = 0 there the same two lines give exactly that
+          // (tn_e = 0); lanes beyond E compute something that is never stored.
 #if COLATE_ABL_HAS(4)
-            q_e[c] = 1.0 - x_e[c];
+          const double qx = 1.0 - x_e[c];
 #else
-            q_e[c] = em::em_exp_t(-x_e[c], s_exptab);
+          const double qx = em::em_exp_t(-x_e[c], s_exptab);
 #endif
-            if (valid) {
-              p_e[c] = 1.0 - q_e[c];                                  // exp(A_ep + cs), coal_EM.cpp:119
-              beta_e[c] = (t_e[c] + inv) - (tn_e[c] + inv) * q_e[c];  // exp(B_ep + cs), coal_EM.cpp:120
-            }
-          } else if (e == E - 1 && valid) {  // last epoch, coal_EM.cpp:136-141
-            p_e[c] = 1.0;
-            beta_e[c] = t_e[c] + inv;
-          }
+          q_e[c] = (e < E - 1) ? qx : 0.0;
+          p_e[c] = valid ? 1.0 - q_e[c] : 0.0;                                  // exp(A_ep + cs), coal_EM.cpp:119
+          beta_e[c] = valid ? (t_e[c] + inv) - (tn_e[c] + inv) * q_e[c] : 0.0;  // exp(B_ep + cs), coal_EM.cpp:120
           if (ep_on[c]) {
             s_ep[G_LAM * EPAD + e] = lam_e[c];
             s_ep[G_INV * EPAD + e] = inv;
@@ -649,17 +649,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
             fail = true;
           }
         } else {  // ---- EM_notshared, coal_EM.cpp:330-357, 435-460
-          if (last_bin) {  // bin beyond the start of the last epoch, coal_EM.cpp:350-357
-            if (!lpos) my_flags |= COLATE_FLAG_NAN;  // reference: assert(coal_rate_e > 0)
-            double dk = (a_b + ik) - tk;
-            dk = __builtin_fmax(dk, 0.0);
-            o_N = cnt;
-            o_D = cnt * dk;
-            if (need_ll) {
-              COLATE_COLD();
-              llp = cnt * neg_cs_age();
-            }
-          } else {
+          // every live lane takes the general path (db = 0 in the last epoch, so it is harmless there); the few bins
+          // beyond the start of the last epoch are put right afterwards, behind a wave-uniform test
+          {
 #if COLATE_ABL_HAS(6)
             const double u = 1.0 - lk * db;
 #else
@@ -667,7 +659,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #endif
             const double pn = lpos ? 1.0 - u : 0.0;
             const double bn = lpos ? (a_b + ik) - (tkn + ik) * u : 0.0;
-            if (absorbing) {  // normaliser = exp(-cs(age)) * ((1 - u) + u) = exp(-cs(age))
+            if (__builtin_expect(absorbing, 1)) {  // normaliser = exp(-cs(age)) * ((1 - u) + u) = exp(-cs(age))
               double dk = bn + (-tk * pn + dtk * (1.0 - pn));
               dk = __builtin_fmax(dk, 0.0);
               o_w = cnt * u;
@@ -695,6 +687,19 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
               }
             }
           }
+          if (__builtin_expect(__any(last_bin), 0)) {
+            COLATE_COLD();
+            if (last_bin) {  // bin beyond the start of the last epoch, coal_EM.cpp:350-357
+              if (!lpos) my_flags |= COLATE_FLAG_NAN;  // reference: assert(coal_rate_e > 0)
+              double dk = (a_b + ik) - tk;
+              dk = __builtin_fmax(dk, 0.0);
+              o_w = 0.0;
+              o_N = cnt;
+              o_D = cnt * dk;
+              fail = false;
+              llp = need_ll ? cnt * neg_cs_age() : 0.0;
+            }
+          }
         }
       }
       COLATE_STAMP(1)
@@ -705,15 +710,14 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         if (lane == 0) s_fail[wslot] = any_fail ? 1 : 0;
       } else {
         const bool any_fail = __any(fail);
-        if (fail || wrote_fail) {  // publish, or clear what this lane published last time
+        if (__builtin_expect(any_fail || flag_set, 0)) {  // (uniform) something to publish, or to clear from last time
           COLATE_COLD();
-          s_cfail[ROLE * APZ + pos] = fail ? cnt : 0.0;
-        }
-        wrote_fail = fail;
-        if (any_fail != flag_set) {  // (uniform) publish the per-wave flag only when it changes
-          COLATE_COLD();
-          if (lane == 0) s_fail[wslot] = any_fail ? 1 : 0;
-          flag_set = any_fail;
+          if (fail || wrote_fail) s_cfail[ROLE * APZ + pos] = fail ? cnt : 0.0;
+          wrote_fail = fail;
+          if (any_fail != flag_set) {  // the per-wave flag only when it changes
+            if (lane == 0) s_fail[wslot] = any_fail ? 1 : 0;
+            flag_set = any_fail;
+          }
         }
       }
       // sums over the run of equal-epoch bins inside each 16-lane row, left to right
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         b.tkn = (b.kb < E - 1) ? s_t[b.kb + 1] : 0.0;
         b.dtk = (b.kb < E - 1) ? b.tkn - b.tk : 0.0;
         b.da = b.a_b - b.tk;
-        b.db = b.tkn - b.a_b;
+        b.db = (b.kb < E - 1) ? b.tkn - b.a_b : 0.0;
         b.f1 = (fl & BF_F1) ? 1.0 : 0.0;
         b.f2 = (fl & BF_F2) ? 1.0 : 0.0;
         b.f4 = (fl & BF_F4) ? 1.0 : 0.0;
@@ -799,7 +803,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         w[c] = (w0 + w1) + w2;
         oN[c] = (n0 + n1) + n2;
         oD[c] = ((d0 + d1) + d2) + eta_e[c];  // (the residue joins the own-epoch sum: off the scan's dependency chain)
-        for (int r = row_x[c]; r <= row_hi[c]; r++) {
+        if (__builtin_expect(more_rows[c], 0)) for (int r = row_x[c]; r <= row_hi[c]; r++) {
           COLATE_COLD();
           int slot = r * 16 + 15;
           if (slot > seg_hi[c] - 1) slot = seg_hi[c] - 1;
@@ -814,7 +818,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #pragma unroll
       for (int c = 0; c < NCH; c++) Cn[c] = C0[c];
       {
-        if (anyf) {
+        if (__builtin_expect(anyf != 0, 0)) {
           COLATE_COLD();
 #pragma unroll
           for (int c = 0; c < NCH; c++) {
@@ -849,17 +853,15 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           const double VW = S_e[c] * beta_e[c] - t_e[c] * W;   // exp(B_ep) - t_e exp(A_ep)
           const double PWn = omS_e[c] + W;                     // sum_{j<=e} exp(A_ep[j])
           Npart[c] = W * RSn[c] + oN[c];
-          if (e < E - 1) {
-            // sum_b c_b (exp(B_e - Z_b) - t_e num_e(b) + dt_e integ_e(b)) over the shared bins of later epochs;
-            // the reference clamps every bin's term at 0 (coal_EM.cpp:277), here the (non-negative) sums are
-            double integ = Cn[c] - PWn * RSn[c];  // sum_b c_b (1 - r_b PW_{e+1})
-            integ = __builtin_fmax(integ, 0.0);
-            double dsh = VW * RSn[c] + dt_e[c] * integ;
-            dsh = __builtin_fmax(dsh, 0.0);
-            Dpart[c] = dsh + oD[c];
-          } else {
-            Dpart[c] = oD[c];
-          }
+          // sum_b c_b (exp(B_e - Z_b) - t_e num_e(b) + dt_e integ_e(b)) over the shared bins of later epochs;
+          // the reference clamps every bin's term at 0 (coal_EM.cpp:277), here the (non-negative) sums are.
+          // (No branch on the last epoch: dt_e = 0 and RS = 0 there, the term vanishes by itself.)
+          double integ = Cn[c] - PWn * RSn[c];  // sum_b c_b (1 - r_b PW_{e+1})
+          integ = __builtin_fmax(integ, 0.0);
+          double dsh = VW * RSn[c] + dt_e[c] * integ;
+          dsh = __builtin_fmax(dsh, 0.0);
+          Dpart[c] = dsh + oD[c];
+          (void)e;
         }
       } else {
         // forward recurrence T_{e+1} = q_e T_e + h_e, T_0 = 0
@@ -881,21 +883,16 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         for (int c = 0; c < NCH; c++) {
           const int e = c * kWave + lane;
           Npart[c] = p_e[c] * T[c] + oN[c];
-          if (e < E - 1) {
-            double Gn = 1.0;  // mass still to coalesce after t_{e+1}, relative to survival there
-            if (!absorbing) {
-              COLATE_COLD();
-              Gn = 1.0 - em::em_exp_t(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + e + 1], s_exptab);
-            }
-            // later not-shared bins contribute dt_e each, earlier ones their tail mass
-            double dns = dt_e[c] * Cn[c] + ((beta_e[c] - t_e[c] * p_e[c]) * T[c] + dt_e[c] * Gn * (q_e[c] * T[c]));
-            dns = __builtin_fmax(dns, 0.0);
-            Dpart[c] = dns + oD[c];
-          } else {
-            double dns = (beta_e[c] - t_e[c] * p_e[c]) * T[c];
-            dns = __builtin_fmax(dns, 0.0);
-            Dpart[c] = dns + oD[c];
+          double Gn = 1.0;  // mass still to coalesce after t_{e+1}, relative to survival there
+          if (__builtin_expect(!absorbing, 0)) {
+            COLATE_COLD();
+            if (e < E - 1) Gn = 1.0 - em::em_exp_t(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + e + 1], s_exptab);
           }
+          // later not-shared bins contribute dt_e each, earlier ones their tail mass (last epoch: dt_e = 0 and q_e = 0
+          // leave (beta - t p) T, coal_EM.cpp:136-141, without a branch)
+          double dns = dt_e[c] * Cn[c] + ((beta_e[c] - t_e[c] * p_e[c]) * T[c] + dt_e[c] * Gn * (q_e[c] * T[c]));
+          dns = __builtin_fmax(dns, 0.0);
+          Dpart[c] = dns + oD[c];
         }
       }
 #pragma unroll
@@ -959,7 +956,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         if (cp && (lower_keep || (cp & (cp + 1ull)))) simple = false;
         if (keep[c]) lower_keep = true;
       }
-      if (kRole != 1 && tracker) {  // scalar masks for the epilogue's verdict, kept by a wave that has time for it
+      if (kRole != 1 && __builtin_expect(tracker, kLeader == 0)) {  // scalar masks for the epilogue's verdict, kept by a wave that has time for it
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           ever_tiny[c] |= __ballot(ep_on[c] && !(N_e[c] >= kTinyNum));
@@ -967,7 +964,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           ever_noisy |= __ballot(ep_on[c] && N_e[c] != 0.0 && D_e[c] < noisy_thr[c] && cand[c] > p.rate_floor);
         }
       }
-      if (simple) {
+      if (__builtin_expect(simple, 1)) {
 #pragma unroll
         for (int c = 0; c < NCH; c++) lam_e[c] = ((keep[c] >> lane) & 1ull) ? cand[c] : 0.0;
       } else {
