@@ -533,11 +533,11 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #else
           S_e[c] = em::em_exp_om_t(-cs_e[c], &omS_e[c], s_exptab);  // omS = 1 - S_e = sum_{j<e} exp(A_ep[j])
 #endif
-          if (ep_on[c]) {
-            s_ep[G_CS * EPAD + e] = cs_e[c];
-            s_ep[G_S * EPAD + e] = S_e[c];
-            s_ep[G_PW * EPAD + e] = omS_e[c];
-          }
+          // (no `if (ep_on)`: the rows are EPAD wide, entries beyond E are written with whatever the idle lanes hold and
+          // never read for an epoch; a not-taken skip branch costs a lone wave 8 cycles, its exec bookkeeping 10 more)
+          s_ep[G_CS * EPAD + e] = cs_e[c];
+          s_ep[G_S * EPAD + e] = S_e[c];
+          s_ep[G_PW * EPAD + e] = omS_e[c];
         }
       } else {
 #pragma unroll
@@ -561,17 +561,15 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           q_e[c] = (e < E - 1) ? qx : 0.0;
           p_e[c] = valid ? 1.0 - q_e[c] : 0.0;                                  // exp(A_ep + cs), coal_EM.cpp:119
           beta_e[c] = valid ? (t_e[c] + inv) - (tn_e[c] + inv) * q_e[c] : 0.0;  // exp(B_ep + cs), coal_EM.cpp:120
-          if (ep_on[c]) {
-            s_ep[G_LAM * EPAD + e] = lam_e[c];
-            s_ep[G_INV * EPAD + e] = inv;
+          s_ep[G_LAM * EPAD + e] = lam_e[c];
+          s_ep[G_INV * EPAD + e] = inv;
 #if COLATE_ABL_HAS(7)
-            s_ep[G_XA * EPAD + e] = (t_e[c] + inv) * lam_e[c];
+          s_ep[G_XA * EPAD + e] = (t_e[c] + inv) * lam_e[c];
 #else
-            s_ep[G_XA * EPAD + e] = em::em_div_known_rcp(t_e[c] + inv, inv, lam_e[c]);  // (t + 1/lambda)/(1/lambda), coal_EM.cpp:204
+          s_ep[G_XA * EPAD + e] = em::em_div_known_rcp(t_e[c] + inv, inv, lam_e[c]);  // (t + 1/lambda)/(1/lambda), coal_EM.cpp:204
 #endif
-            s_ep[G_P * EPAD + e] = p_e[c];
-            s_ep[G_BETA * EPAD + e] = beta_e[c];
-          }
+          s_ep[G_P * EPAD + e] = p_e[c];
+          s_ep[G_BETA * EPAD + e] = beta_e[c];
         }
       }
     }
@@ -659,7 +657,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #endif
             const double pn = lpos ? 1.0 - u : 0.0;
             const double bn = lpos ? (a_b + ik) - (tkn + ik) * u : 0.0;
-            if (__builtin_expect(absorbing, 1)) {  // normaliser = exp(-cs(age)) * ((1 - u) + u) = exp(-cs(age))
+            {  // the last epoch absorbs: normaliser = exp(-cs(age)) * ((1 - u) + u) = exp(-cs(age))
               double dk = bn + (-tk * pn + dtk * (1.0 - pn));
               dk = __builtin_fmax(dk, 0.0);
               o_w = cnt * u;
@@ -669,10 +667,12 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
                 COLATE_COLD();
                 llp = cnt * neg_cs_age();
               }
-            } else {  // last rate is 0: the mass beyond t_{k+1} is 1 - S_{E-1}/S_{k+1}
+            }
+            if (__builtin_expect(!absorbing, 0)) {  // last rate is 0: the mass beyond t_{k+1} is 1 - S_{E-1}/S_{k+1}
               COLATE_COLD();
               const double Gk1 = 1.0 - em::em_exp_t(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + kb + 1], s_exptab);
               const double SigN = pn + u * Gk1;
+              o_w = o_N = o_D = llp = 0.0;
               if (finite_pos(SigN)) {
                 const double rr = 1.0 / SigN;
                 const double nk = pn * rr;
@@ -732,10 +732,11 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       COLATE_SEG_STEP(ROW_SHR8, f8)
 #endif
 #undef COLATE_SEG_STEP
-      if (is_tail) {
-        out_mine[O_W * APZ + pos] = o_w;
-        out_mine[O_N * APZ + pos] = o_N;
-        out_mine[O_D * APZ + pos] = o_D;
+      {  // (no branch: lanes that are not the tail of a run write to the spare entry AP + 1, which nobody reads)
+        const int tpos = is_tail ? pos : AP + 1;
+        out_mine[O_W * APZ + tpos] = o_w;
+        out_mine[O_N * APZ + tpos] = o_N;
+        out_mine[O_D * APZ + tpos] = o_D;
       }
       if (need_ll) {
         COLATE_COLD();
@@ -897,10 +898,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       }
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
-        if (ep_on[c]) {
-          s_nd[(ROLE * 2 + 0) * EPAD + c * kWave + lane] = Npart[c];
-          s_nd[(ROLE * 2 + 1) * EPAD + c * kWave + lane] = Dpart[c];
-        }
+        s_nd[(ROLE * 2 + 0) * EPAD + c * kWave + lane] = Npart[c];
+        s_nd[(ROLE * 2 + 1) * EPAD + c * kWave + lane] = Dpart[c];
       }
     }
     COLATE_STAMP(4)
@@ -942,14 +941,14 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         const bool copy = (N_e[c] == 0);
-        cand[c] = lam_e[c];
-        if (!copy && D_e[c] != 0) {
+        {  // (as selects: the quotient is computed in every lane, 0/0 and x/0 included, and dropped where it does not apply)
 #if COLATE_ABL_HAS(10)
-          cand[c] = N_e[c] * 1e-4 + D_e[c] * 1e-9;
+          double qn = N_e[c] * 1e-4 + D_e[c] * 1e-9;
 #else
-          cand[c] = N_e[c] / D_e[c];
+          double qn = N_e[c] / D_e[c];
 #endif
-          if (cand[c] < p.rate_floor) cand[c] = p.rate_floor;
+          if (qn < p.rate_floor) qn = p.rate_floor;
+          cand[c] = (!copy && D_e[c] != 0) ? qn : lam_e[c];
         }
         keep[c] = __ballot(ep_on[c] && !copy);
         const unsigned long long cp = __ballot(ep_on[c] && copy);
@@ -1010,19 +1009,26 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     if (n_steady < 0) n_steady = 0;
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
-    if (role == 0) {
-      if (leader) {
-        for (; iter < n_steady; iter++) iteration(C0{}, C1{}, C0{});
+#define COLATE_STEADY(R, L)                                   \
+  do {                                                        \
+    iteration(R{}, L{}, C0{});                                \
+  } while (__builtin_expect(++iter < n_steady, 1))
+    if (iter < n_steady) {
+      if (role == 0) {
+        if (leader) {
+          COLATE_STEADY(C0, C1);
+        } else {
+          COLATE_STEADY(C0, C0);
+        }
       } else {
-        for (; iter < n_steady; iter++) iteration(C0{}, C0{}, C0{});
-      }
-    } else {
-      if (leader) {
-        for (; iter < n_steady; iter++) iteration(C1{}, C1{}, C0{});
-      } else {
-        for (; iter < n_steady; iter++) iteration(C1{}, C0{}, C0{});
+        if (leader) {
+          COLATE_STEADY(C1, C1);
+        } else {
+          COLATE_STEADY(C1, C0);
+        }
       }
     }
+#undef COLATE_STEADY
   }
   for (; iter < max_iter; iter++) {
     using CR = std::integral_constant<int, -1>;

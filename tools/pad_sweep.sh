@@ -6,7 +6,7 @@
 set -euo pipefail
 prefix=${1:-pad}; shift || true
 cd "$(dirname "$0")/../colate_amd/csrc"
-F="-O3 -std=c++17 -fPIC -ffp-contract=off -I$(cd ../..; pwd)/include --offload-arch=gfx950"
+F="-O3 -std=c++17 -fPIC -ffp-contract=off -I$(cd ../..; pwd)/include --offload-arch=gfx950 -mllvm -force-precise-rotation-cost=true"
 make > /dev/null
 for n in 0 1 2 3 4 5 6 7; do
   /opt/rocm/bin/hipcc $F "$@" -mllvm -amdgpu-sched-strategy=max-ilp -DCOLATE_LOOP_PAD=$n -c em_kernels_ilp.hip -o /tmp/ilp_$prefix$n.o &
