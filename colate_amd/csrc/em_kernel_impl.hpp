@@ -492,10 +492,12 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     COLATE_PAD_CASE(4) COLATE_PAD_CASE(5) COLATE_PAD_CASE(6) COLATE_PAD_CASE(7)
 #undef COLATE_PAD_CASE
   }
-  auto iteration = [&](auto role_c, auto leader_c, auto ll_c) __attribute__((always_inline)) -> bool {
+  auto iteration = [&](auto role_c, auto leader_c, auto ll_c, auto track_c) __attribute__((always_inline)) -> bool {
     COLATE_STAMP(7)
     // (compile-time role / leadership / "no log-likelihood needed" in the steady-state loops below; -1 = run-time value)
     constexpr int kRole = decltype(role_c)::value, kLeader = decltype(leader_c)::value, kNeedLL = decltype(ll_c)::value;
+    constexpr int kTrack = decltype(track_c)::value;  // this wave keeps the verdict's history masks (1), does not (0)
+    constexpr bool kSteady = (kNeedLL == 0);          // a steady-state loop: no wave with `more_rows` runs it
     const int ROLE = kRole < 0 ? role : kRole;
     const bool LEADER = kLeader < 0 ? leader : (kLeader != 0);
     const bool need_ll = kNeedLL < 0 ? ((MODE == 1) || (iter >= p.min_iter) || (iter == max_iter - 1)) : (kNeedLL != 0);
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         w[c] = (w0 + w1) + w2;
         oN[c] = (n0 + n1) + n2;
         oD[c] = ((d0 + d1) + d2) + eta_e[c];  // (the residue joins the own-epoch sum: off the scan's dependency chain)
-        if (__builtin_expect(more_rows[c], 0)) for (int r = row_x[c]; r <= row_hi[c]; r++) {
+        if (!kSteady && __builtin_expect(more_rows[c], 0)) for (int r = row_x[c]; r <= row_hi[c]; r++) {
           COLATE_COLD();
           int slot = r * 16 + 15;
           if (slot > seg_hi[c] - 1) slot = seg_hi[c] - 1;
@@ -936,8 +938,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     if (!COLATE_ABL_HAS(14)) {
       double cand[NCH];
       unsigned long long keep[NCH];  // epochs that do NOT copy their predecessor
-      bool simple = true;            // the copying epochs form a prefix 0..m-1: they all become 0
-      bool lower_keep = false;
+      // the copying epochs form a prefix 0..m-1 (they all become 0) unless a bit of `bad` is set: as scalar mask
+      // arithmetic, so that one compare and one branch decide
+      unsigned long long bad = 0, lower_keep = 0;  // lower_keep: all ones once an earlier chunk holds a keeper
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         const bool copy = (N_e[c] == 0);
@@ -952,10 +955,10 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         }
         keep[c] = __ballot(ep_on[c] && !copy);
         const unsigned long long cp = __ballot(ep_on[c] && copy);
-        if (cp && (lower_keep || (cp & (cp + 1ull)))) simple = false;
-        if (keep[c]) lower_keep = true;
+        bad |= (cp & (cp + 1ull)) | (lower_keep & cp);
+        lower_keep |= keep[c] ? ~0ull : 0ull;
       }
-      if (kRole != 1 && __builtin_expect(tracker, kLeader == 0)) {  // scalar masks for the epilogue's verdict, kept by a wave that has time for it
+      if (kTrack < 0 ? tracker : (kTrack != 0)) {  // scalar masks for the epilogue's verdict, kept by a wave that has time for it
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           ever_tiny[c] |= __ballot(ep_on[c] && !(N_e[c] >= kTinyNum));
@@ -963,7 +966,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           ever_noisy |= __ballot(ep_on[c] && N_e[c] != 0.0 && D_e[c] < noisy_thr[c] && cand[c] > p.rate_floor);
         }
       }
-      if (__builtin_expect(simple, 1)) {
+      if (__builtin_expect(bad == 0, 1)) {
 #pragma unroll
         for (int c = 0; c < NCH; c++) lam_e[c] = ((keep[c] >> lane) & 1ull) ? cand[c] : 0.0;
       } else {
@@ -1009,22 +1012,34 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     if (n_steady < 0) n_steady = 0;
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
-#define COLATE_STEADY(R, L)                                   \
+#define COLATE_STEADY(R, L, T)                                \
   do {                                                        \
-    iteration(R{}, L{}, C0{});                                \
+    iteration(R{}, L{}, C0{}, T{});                           \
   } while (__builtin_expect(++iter < n_steady, 1))
+    bool any_more_rows = false;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) any_more_rows |= more_rows[c];
+    if (any_more_rows) n_steady = 0;  // (an epoch spanning more than 48 data bins: this wave stays in the general loop)
     if (iter < n_steady) {
-      if (role == 0) {
+      if (role == 0) {  // (the wave that keeps the verdict's history is of role 0: wave 0 or wave 2)
         if (leader) {
-          COLATE_STEADY(C0, C1);
+          if (tracker) {
+            COLATE_STEADY(C0, C1, C1);
+          } else {
+            COLATE_STEADY(C0, C1, C0);
+          }
         } else {
-          COLATE_STEADY(C0, C0);
+          if (tracker) {
+            COLATE_STEADY(C0, C0, C1);
+          } else {
+            COLATE_STEADY(C0, C0, C0);
+          }
         }
       } else {
         if (leader) {
-          COLATE_STEADY(C1, C1);
+          COLATE_STEADY(C1, C1, C0);
         } else {
-          COLATE_STEADY(C1, C0);
+          COLATE_STEADY(C1, C0, C0);
         }
       }
     }
@@ -1032,7 +1047,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   }
   for (; iter < max_iter; iter++) {
     using CR = std::integral_constant<int, -1>;
-    if (iteration(CR{}, CR{}, CR{})) break;
+    if (iteration(CR{}, CR{}, CR{}, CR{})) break;
   }
 
 #ifdef COLATE_EM_STAMPS
