@@ -438,8 +438,12 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     }
   }
   bool more_rows[NCH];  // (wave-uniform) some epoch of the chunk spans more than three 16-lane rows
+  bool third_row = false;  // ... more than two (the steady-state loops read two tail slots per epoch, not three)
 #pragma unroll
-  for (int c = 0; c < NCH; c++) more_rows[c] = __any(row_x[c] <= row_hi[c]);
+  for (int c = 0; c < NCH; c++) {
+    more_rows[c] = __any(row_x[c] <= row_hi[c]);
+    third_row |= __any(slot2[c] != AP);
+  }
   __syncthreads();
   if (!TPUT && grp >= NB) return;  // waves without bins retire; later barriers count the remaining waves only
   const bool leader = (grp == 0);
@@ -795,17 +799,21 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #if COLATE_ABL_HAS(1)  // ablation: no tail loads
         const double w0 = 1e-3 * lane, w1 = 0, w2 = 0, n0 = 1e-3, n1 = 0, n2 = 0, d0 = 1.0, d1 = 0, d2 = 0;
 #else
-        const double w0 = out_mine[O_W * APZ + slot0[c]], w1 = out_mine[O_W * APZ + slot1[c]], w2 = out_mine[O_W * APZ + slot2[c]];
-        const double n0 = out_mine[O_N * APZ + slot0[c]], n1 = out_mine[O_N * APZ + slot1[c]], n2 = out_mine[O_N * APZ + slot2[c]];
-        const double d0 = out_mine[O_D * APZ + slot0[c]], d1 = out_mine[O_D * APZ + slot1[c]], d2 = out_mine[O_D * APZ + slot2[c]];
+        const double w0 = out_mine[O_W * APZ + slot0[c]], w1 = out_mine[O_W * APZ + slot1[c]];
+        const double n0 = out_mine[O_N * APZ + slot0[c]], n1 = out_mine[O_N * APZ + slot1[c]];
+        const double d0 = out_mine[O_D * APZ + slot0[c]], d1 = out_mine[O_D * APZ + slot1[c]];
+        // (a run of equal-epoch bins reaching into a third row: never in a wave that runs a steady-state loop; adding
+        // the zero entry there would give the same sums)
+        const double w2 = kSteady ? 0.0 : out_mine[O_W * APZ + slot2[c]], n2 = kSteady ? 0.0 : out_mine[O_N * APZ + slot2[c]];
+        const double d2 = kSteady ? 0.0 : out_mine[O_D * APZ + slot2[c]];
 #endif
-        if (ROLE == 0) {  // the shared LEADER also needs the not-shared LEADER's p_e, beta_e
+        if (ROLE == 0) {  // the shared leader also needs the not-shared leader's p_e, beta_e
           p_e[c] = s_ep[G_P * EPAD + c * kWave + lane];
           beta_e[c] = s_ep[G_BETA * EPAD + c * kWave + lane];
         }
-        w[c] = (w0 + w1) + w2;
-        oN[c] = (n0 + n1) + n2;
-        oD[c] = ((d0 + d1) + d2) + eta_e[c];  // (the residue joins the own-epoch sum: off the scan's dependency chain)
+        w[c] = kSteady ? (w0 + w1) : (w0 + w1) + w2;  // (x + 0.0 == x for the non-negative sums here: same bits)
+        oN[c] = kSteady ? (n0 + n1) : (n0 + n1) + n2;
+        oD[c] = (kSteady ? (d0 + d1) : (d0 + d1) + d2) + eta_e[c];  // (the residue joins the own-epoch sum: off the scan's dependency chain)
         if (!kSteady && __builtin_expect(more_rows[c], 0)) for (int r = row_x[c]; r <= row_hi[c]; r++) {
           COLATE_COLD();
           int slot = r * 16 + 15;
@@ -1019,7 +1027,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     bool any_more_rows = false;
 #pragma unroll
     for (int c = 0; c < NCH; c++) any_more_rows |= more_rows[c];
-    if (any_more_rows) n_steady = 0;  // (an epoch spanning more than 48 data bins: this wave stays in the general loop)
+    if (any_more_rows || third_row) n_steady = 0;  // (an epoch spanning more than two rows of data bins: this wave stays in the general loop)
     if (iter < n_steady) {
       if (role == 0) {  // (the wave that keeps the verdict's history is of role 0: wave 0 or wave 2)
         if (leader) {
