@@ -501,7 +501,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     // (compile-time role / leadership / "no log-likelihood needed" in the steady-state loops below; -1 = run-time value)
     constexpr int kRole = decltype(role_c)::value, kLeader = decltype(leader_c)::value, kNeedLL = decltype(ll_c)::value;
     constexpr int kTrack = decltype(track_c)::value;  // this wave keeps the verdict's history masks (1), does not (0)
-    constexpr bool kSteady = (kNeedLL == 0);          // a steady-state loop: no wave with `more_rows` runs it
+    constexpr bool kSteady = (kNeedLL >= 0);          // one of the loops compiled per kind of wave: no wave with `more_rows` / `third_row` runs it
     const int ROLE = kRole < 0 ? role : kRole;
     const bool LEADER = kLeader < 0 ? leader : (kLeader != 0);
     const bool need_ll = kNeedLL < 0 ? ((MODE == 1) || (iter >= p.min_iter) || (iter == max_iter - 1)) : (kNeedLL != 0);
@@ -1013,8 +1013,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   // leadership never change -- so each kind of wave runs them in a loop of its own, compiled for exactly that kind: no
   // wave-uniform branch on role / leader / need_ll is left in it.  A taken branch costs a lone wave ~20 cycles and a
   // not-taken one ~8 (csrc/tools/ubench_branch.hip, profiles/r02/ubench_branch.txt), against ~5 for an FP64 instruction.
-  // The waves of a workgroup run different loops but the same sequence of barriers.  The general loop below takes over
-  // from min_iter on (and is all there is for MODE 1).
+  // The waves of a workgroup run different loops but the same sequence of barriers.  The general loop below is what is
+  // left for MODE 1 and for the rare wave whose epochs need more than two tail slots.
+  bool stopped = false;
   if (MODE == 0) {
     int n_steady = p.min_iter < max_iter - 1 ? p.min_iter : max_iter - 1;
     if (n_steady < 0) n_steady = 0;
@@ -1027,33 +1028,49 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     bool any_more_rows = false;
 #pragma unroll
     for (int c = 0; c < NCH; c++) any_more_rows |= more_rows[c];
-    if (any_more_rows || third_row) n_steady = 0;  // (an epoch spanning more than two rows of data bins: this wave stays in the general loop)
-    if (iter < n_steady) {
+    // (a wave with an epoch spanning more than two rows of data bins stays in the general loop)
+    // ... and the iterations from min_iter on (log-likelihood and stop test in every one) in a second set of loops
+    // compiled the same way: runs on sparse tables go on for up to 1e5 iterations there
+#define COLATE_STEADY_LL(R, L, T)                             \
+  for (; iter < max_iter; iter++) {                           \
+    if (iteration(R{}, L{}, C1{}, T{})) {                     \
+      stopped = true;                                         \
+      break;                                                  \
+    }                                                         \
+  }
+#define COLATE_BOTH(R, L, T)                                  \
+  {                                                           \
+    if (iter < n_steady) COLATE_STEADY(R, L, T);              \
+    COLATE_STEADY_LL(R, L, T)                                 \
+  }
+    if (!(any_more_rows || third_row)) {
       if (role == 0) {  // (the wave that keeps the verdict's history is of role 0: wave 0 or wave 2)
         if (leader) {
           if (tracker) {
-            COLATE_STEADY(C0, C1, C1);
+            COLATE_BOTH(C0, C1, C1)
           } else {
-            COLATE_STEADY(C0, C1, C0);
+            COLATE_BOTH(C0, C1, C0)
           }
         } else {
           if (tracker) {
-            COLATE_STEADY(C0, C0, C1);
+            COLATE_BOTH(C0, C0, C1)
           } else {
-            COLATE_STEADY(C0, C0, C0);
+            COLATE_BOTH(C0, C0, C0)
           }
         }
       } else {
         if (leader) {
-          COLATE_STEADY(C1, C1, C0);
+          COLATE_BOTH(C1, C1, C0)
         } else {
-          COLATE_STEADY(C1, C0, C0);
+          COLATE_BOTH(C1, C0, C0)
         }
       }
     }
+#undef COLATE_BOTH
+#undef COLATE_STEADY_LL
 #undef COLATE_STEADY
   }
-  for (; iter < max_iter; iter++) {
+  for (; !stopped && iter < max_iter; iter++) {
     using CR = std::integral_constant<int, -1>;
     if (iteration(CR{}, CR{}, CR{}, CR{})) break;
   }

@@ -36,9 +36,14 @@ int colate_em_variant(int B, int E) {
     if (!strcmp(v, "latency")) return 1;
     if (!strcmp(v, "latency-ilp")) return 0;
   }
+  // Measured (tools/variant_sweep.sh, profiles/r02/variants.txt): since the steady-state loops the max-ilp build fits
+  // 3 waves per SIMD as well (157 VGPRs) and is the faster latency build at every batch size (1.29 against 1.33 ms at
+  // B = 400); two 6-wave workgroups per CU beat the two-wave layout up to 2 x #CUs (B = 512: 1.30 against 2.09 ms),
+  // beyond that the throughput variant wins (B = 640: 2.09 against 2.12 ms; B = 1536: 2.70 against 3.65 ms).  The
+  // default-scheduler latency build stays selectable (COLATE_EM_VARIANT=latency) for A/B runs.
   const int cus = device_cus();
-  if (cus <= 0 || B <= cus) return 0;
-  return B <= 2 * cus ? 1 : 2;
+  if (cus <= 0 || B <= 2 * cus) return 0;
+  return 2;
 }
 
 hipError_t colate_em_launch(const ColateEmArgs& args, hipStream_t stream) {
