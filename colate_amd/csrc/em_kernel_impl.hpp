@@ -1030,7 +1030,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     for (int c = 0; c < NCH; c++) any_more_rows |= more_rows[c];
     // (a wave with an epoch spanning more than two rows of data bins stays in the general loop)
     // ... and the iterations from min_iter on (log-likelihood and stop test in every one) in a second set of loops
-    // compiled the same way: runs on sparse tables go on for up to 1e5 iterations there
+    // compiled the same way: runs on sparse tables go on for up to 1e5 iterations there (1.55 -> 1.31 us per iteration).
+    // Only up to 64 epochs: with two chunks of epochs the extra loops cost the steady ones 2.5 % (1.53 -> 1.57 ms at
+    // E = 122, every code placement; profiles/r02_placement.txt) -- there the general loop takes over at min_iter.
 #define COLATE_STEADY_LL(R, L, T)                             \
   for (; iter < max_iter; iter++) {                           \
     if (iteration(R{}, L{}, C1{}, T{})) {                     \
@@ -1038,11 +1040,18 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       break;                                                  \
     }                                                         \
   }
+#ifdef COLATE_NO_LL_LOOPS  // (A/B switch: the iterations from min_iter on in the general loop)
 #define COLATE_BOTH(R, L, T)                                  \
   {                                                           \
     if (iter < n_steady) COLATE_STEADY(R, L, T);              \
-    COLATE_STEADY_LL(R, L, T)                                 \
   }
+#else
+#define COLATE_BOTH(R, L, T)                                  \
+  {                                                           \
+    if (iter < n_steady) COLATE_STEADY(R, L, T);              \
+    if constexpr (NCH == 1) COLATE_STEADY_LL(R, L, T)         \
+  }
+#endif
     if (!(any_more_rows || third_row)) {
       if (role == 0) {  // (the wave that keeps the verdict's history is of role 0: wave 0 or wave 2)
         if (leader) {
