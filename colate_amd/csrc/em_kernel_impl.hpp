@@ -193,15 +193,16 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput) {
 #else
   (void)erows;
   if (mode != 0) return 0;
-  // measured on MI355X, kernel ms for pads 0..7, final loop code of round 2 (gpurun_out/r02g/padsweep.txt ->
-  // profiles/r02_placement.txt):
+  // measured on MI355X, kernel ms for pads 0..7, final loop code of round 2 (gpurun_out/r02u2/padsweep.txt ->
+  // profiles/r02_placement.txt).  The pad shifts everything behind it, the loops compiled per kind of wave included.
 #ifdef COLATE_EM_ILP_BUILD
-  (void)tput, (void)nch;
-  // latency variant, max-ilp build: E=23 B=100 1.397 1.415 1.425 1.393 1.366 1.381 1.364 1.406; E=122 B=100 2.178 2.168 2.184 2.208 2.245 2.185 2.157 2.179
-  return 6;
+  (void)tput;
+  // latency variant, max-ilp build: E=23 B=100 1.041 1.036 1.043 1.051 1.045 1.051 1.037 1.039 (B=400: 1.254 1.259 1.279 1.269 1.266 1.279 1.271 1.260);
+  // E=122 B=100 1.537 1.553 1.555 1.547 1.537 1.546 1.527 1.547
+  return nch == 1 ? 1 : 6;
 #else
-  if (!tput) return 6;       // latency variant, default build: E=23 B=400 1.649 1.667 1.643 1.635 1.636 1.656 1.621 1.637
-  return nch == 1 ? 1 : 0;   // throughput variant: E=23 B=4096 7.92 7.96 7.95 7.93 7.95 7.93 7.94 7.91 (flat)
+  if (!tput) return 6;       // latency variant, default build (not picked by colate_em_variant any more; COLATE_EM_VARIANT=latency)
+  return nch == 1 ? 1 : 0;   // throughput variant: E=23 B=4096 6.871 6.827 6.893 6.848 6.886 6.858 6.874 6.824
 #endif
 #endif
 }
