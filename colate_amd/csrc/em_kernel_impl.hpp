@@ -167,6 +167,9 @@ __device__ __forceinline__ unsigned long long stamp() {
 
 __device__ __forceinline__ bool finite_pos(double x) { return x > 0.0 && x < __builtin_inf(); }
 
+// the lanes' predicate as a scalar mask, straight from the compare (HIP's __ballot / __any go through a v_cndmask + v_cmp pair)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // wave-local LDS hand-off: earlier ds_writes of this wave are visible to its later ds_reads
 // (the LDS queue is in order per wave); this only stops the compiler from moving them.
 __device__ __forceinline__ void wave_lds_fence() {
@@ -442,8 +445,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   bool third_row = false;  // ... more than two (the steady-state loops read two tail slots per epoch, not three)
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
-    more_rows[c] = __any(row_x[c] <= row_hi[c]);
-    third_row |= __any(slot2[c] != AP);
+    more_rows[c] = (ballot64(row_x[c] <= row_hi[c]) != 0);
+    third_row |= (ballot64(slot2[c] != AP) != 0);
   }
   __syncthreads();
   if (!TPUT && grp >= NB) return;  // waves without bins retire; later barriers count the remaining waves only
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #pragma unroll
   for (int c = 0; c < NCH; c++)  // (only epochs up to the oldest bin with data: the flat ones behind it do not move at all)
     noisy_thr[c] = (double)(c * kWave + lane) <= s_ll[10] ? kNoisyRatio * (dt_e[c] * (kIntegResidue * (s_ll[8] + s_ll[9]))) : 0.0;
-  bool wrote_fail = false, flag_set = false;
+  unsigned long long prev_fail = 0;
   const double thr = 1.0 - p.rel_tol;
   double ll = -__builtin_inf(), prev_ll = -__builtin_inf();  // coal.cpp:3685
   int iter = 0;
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
               }
             }
           }
-          if (__builtin_expect(__any(last_bin), 0)) {
+          if (__builtin_expect(ballot64(last_bin) != 0, 0)) {
             COLATE_COLD();
             if (last_bin) {  // bin beyond the start of the last epoch, coal_EM.cpp:350-357
               if (!lpos) my_flags |= COLATE_FLAG_NAN;  // reference: assert(coal_rate_e > 0)
@@ -711,20 +714,22 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       }
       COLATE_STAMP(1)
       // bins whose normaliser failed (coal_EM.cpp:288-292, 461-465) drop out of the static counts
+      // (s_fail: one byte per wave, the four bin groups of a role in one 32-bit word for the leader's single read)
+      unsigned char* s_failb = reinterpret_cast<unsigned char*>(s_fail);
+      const unsigned long long fail_mask = ballot64(fail);
       if (TPUT) {  // (a wave serves several groups: publish every time)
         s_cfail[ROLE * APZ + pos] = fail ? cnt : 0.0;
-        const bool any_fail = __any(fail);
-        if (lane == 0) s_fail[wslot] = any_fail ? 1 : 0;
+        if (lane == 0) s_failb[ROLE * 4 + (pos >> 6)] = fail_mask ? 1 : 0;
       } else {
-        const bool any_fail = __any(fail);
-        if (__builtin_expect(any_fail || flag_set, 0)) {  // (uniform) something to publish, or to clear from last time
+        // prev_fail: the lanes this wave published a failed bin for in the previous iteration
+        const unsigned long long touch = fail_mask | prev_fail;
+        if (__builtin_expect(touch != 0, 0)) {  // (uniform) something to publish, or to clear from last time
           COLATE_COLD();
-          if (fail || wrote_fail) s_cfail[ROLE * APZ + pos] = fail ? cnt : 0.0;
-          wrote_fail = fail;
-          if (any_fail != flag_set) {  // the per-wave flag only when it changes
-            if (lane == 0) s_fail[wslot] = any_fail ? 1 : 0;
-            flag_set = any_fail;
+          if ((touch >> lane) & 1ull) s_cfail[ROLE * APZ + pos] = fail ? cnt : 0.0;
+          if ((fail_mask != 0) != (prev_fail != 0)) {  // the per-wave flag only when it changes
+            if (lane == 0) s_failb[ROLE * 4 + (pos >> 6)] = fail_mask ? 1 : 0;
           }
+          prev_fail = fail_mask;
         }
       }
       // sums over the run of equal-epoch bins inside each 16-lane row, left to right
@@ -793,7 +798,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     if (LEADER && !COLATE_ABL_HAS(13)) {
       // did a bin of this ROLE fail this iteration? (entries of retired waves stay 0; loaded with the
       // tails: one LDS wait; fixed count -- a runtime-bounded loop here compiles to a vectorised monster)
-      const int anyf = s_fail[ROLE] | s_fail[2 + ROLE] | s_fail[4 + ROLE] | s_fail[6 + ROLE];
+      const int anyf = s_fail[ROLE];  // (four bytes: this role's bin groups)
       double w[NCH], oN[NCH], oD[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
@@ -962,17 +967,17 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           if (qn < p.rate_floor) qn = p.rate_floor;
           cand[c] = (!copy && D_e[c] != 0) ? qn : lam_e[c];
         }
-        keep[c] = __ballot(ep_on[c] && !copy);
-        const unsigned long long cp = __ballot(ep_on[c] && copy);
+        keep[c] = ballot64(ep_on[c] && !copy);
+        const unsigned long long cp = ballot64(ep_on[c] && copy);
         bad |= (cp & (cp + 1ull)) | (lower_keep & cp);
         lower_keep |= keep[c] ? ~0ull : 0ull;
       }
       if (kTrack < 0 ? tracker : (kTrack != 0)) {  // scalar masks for the epilogue's verdict, kept by a wave that has time for it
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-          ever_tiny[c] |= __ballot(ep_on[c] && !(N_e[c] >= kTinyNum));
-          ever_nonzero[c] |= __ballot(ep_on[c] && N_e[c] != 0.0);
-          ever_noisy |= __ballot(ep_on[c] && N_e[c] != 0.0 && D_e[c] < noisy_thr[c] && cand[c] > p.rate_floor);
+          ever_tiny[c] |= ballot64(ep_on[c] && !(N_e[c] >= kTinyNum));
+          ever_nonzero[c] |= ballot64(ep_on[c] && N_e[c] != 0.0);
+          ever_noisy |= ballot64(ep_on[c] && N_e[c] != 0.0 && D_e[c] < noisy_thr[c] && cand[c] > p.rate_floor);
         }
       }
       if (__builtin_expect(bad == 0, 1)) {
@@ -1141,7 +1146,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       const bool path_dependent = (double)e > s_ll[10] && ever_noisy != 0;
       const bool resolved = !ep_on[c] || (!snapshot && !drifted && !path_dependent &&
                             (D >= kResolvedRatio * eta || (lam_e[c] <= p.rate_floor && D < 3.0 * eta)));
-      const unsigned long long bad = __ballot(!resolved);
+      const unsigned long long bad = ballot64(!resolved);
       if (bad) first_bad = c * kWave + __builtin_ctzll(bad);
     }
     if (lane == 0) s_misc[3] = E - first_bad;

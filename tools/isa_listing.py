@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
-"""ISA of the EM loop of one kernel instantiation, cut into the phases of an iteration (at its s_barrier instructions)
-with instruction-class counts per phase: the listing committed as profiles/r02_isa_loop_<name>.txt.
+"""ISA of the steady-state EM loops of one kernel instantiation -- one loop per kind of wave (role x leadership x keeps the
+verdict history), see the end of em_kernel in colate_amd/csrc/em_kernel_impl.hpp -- cut into the phases of an iteration at
+the s_barrier instructions, with instruction-class counts per phase and every branch marked with its direction: the listing
+committed as profiles/r02_isa_loop_<name>.txt.
 
     python tools/isa_listing.py 'em_kernelILi0ELi1ELi2ELb0' > profiles/r02_isa_loop_e23_latency_ilp.txt
 
-Builds colate_amd/csrc/em_kernels_ilp.hip with the Makefile's flags to a device ELF and disassembles it
-(llvm-objdump).  Static counts over ALL paths of a phase (both roles, cold paths included): the two role leaders
-execute disjoint exec-masked halves of P1 and P3, every live wave executes P2 (its own role's half) and P4."""
+Builds colate_amd/csrc/em_kernels_ilp.hip with the Makefile's flags (+ line tables) to a device ELF and disassembles it
+(llvm-objdump -l).  A loop is a backward branch over exactly three barriers; the COLATE_BOTH(...) line its iteration counter
+is attributed to tells which kind of wave it is for; its address range is listed whole, so a block the compiler placed out of line but inside the range
+(role B's leader has some) shows up between the phases: blocks are separated by a blank line wherever a branch target or
+the instruction behind an unconditional branch starts one."""
 import collections
 import os
 import re
@@ -16,32 +20,41 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pat = sys.argv[1] if len(sys.argv) > 1 else "em_kernelILi0ELi1ELi2ELb0"
 src = os.path.join(ROOT, "colate_amd", "csrc", "em_kernels_ilp.hip")
+impl = os.path.join(ROOT, "colate_amd", "csrc", "em_kernel_impl.hpp")
 elf = "/tmp/isa_listing.elf"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-I{ROOT}/include",
-                       "--offload-arch=gfx950", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-force-precise-rotation-cost=true", "--cuda-device-only", "-c",
-                       "--no-gpu-bundle-output", src, "-o", elf], stderr=subprocess.DEVNULL)
-dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", elf], text=True).split("\n")
+                       "--offload-arch=gfx950", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-force-precise-rotation-cost=true",
+                       "-gline-tables-only", "--cuda-device-only", "-c", "--no-gpu-bundle-output", src, "-o", elf], stderr=subprocess.DEVNULL)
+dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "-l", elf], text=True).split("\n")
 start = [i for i, l in enumerate(dis) if re.match(r"^[0-9a-f]+ <.*" + re.escape(pat) + r".*>:$", l)][0]
 end = next(i for i in range(start + 1, len(dis)) if re.match(r"^[0-9a-f]+ <.*>:$", dis[i]))
-body = [l for l in dis[start + 1:end] if l.strip()]
-ins = []
-for l in body:
+impl_lines = open(impl).read().split("\n")
+ins = []  # (address, op, args, source line in em_kernel_impl.hpp or None)
+cur = None
+for l in dis[start + 1:end]:
+    m = re.match(r"^; (/\S+):(\d+)", l)
+    if m:
+        cur = int(m.group(2)) if m.group(1).endswith("em_kernel_impl.hpp") else None
+        continue
     m = re.match(r"\s+(\S+)\s*(.*?)\s*//\s*([0-9A-F]+):", l)
     if m:
-        ins.append((int(m.group(3), 16), m.group(1), m.group(2)))
-bars = [k for k, (_, op, _) in enumerate(ins) if op == "s_barrier"]
-# the loop: barriers 1..3 are the last three before the epilogue's; the back edge is the last branch to an address before barrier 1
-b1, b2, b3 = bars[-4], bars[-3], bars[-2]
+        ins.append((int(m.group(3), 16), m.group(1), m.group(2), cur))
+addr0 = ins[0][0]
+index = {a: k for k, (a, _, _, _) in enumerate(ins)}
 
+
+def target(a, args):
+    off = int(re.search(r"(-?\d+)", args).group(1))
+    off = off - 65536 if off > 32767 else off  # (the disassembler prints the 16-bit field unsigned)
+    return a + 4 + 4 * off
 
 
 def cls(op, args):
     if op.startswith("v_") and "dpp" in op + args:
         return "VALU dpp mov"
-    if op.startswith(("v_fma_f64", "v_fmac_f64", "v_mul_f64", "v_add_f64", "v_max_f64", "v_min_f64", "v_ldexp_f64", "v_rcp_f64",
-                      "v_div_", "v_rndne_f64", "v_frexp", "v_cmp_", "v_cvt_f64", "v_trig")) and "f64" in op:
+    if op.startswith("v_") and "f64" in op:
         return "VALU f64"
-    if op.startswith("v_readlane") or op.startswith("v_readfirstlane") or op.startswith("v_writelane"):
+    if op.startswith(("v_readlane", "v_readfirstlane", "v_writelane")):
         return "VALU lane<->scalar"
     if op.startswith("v_"):
         return "VALU other"
@@ -49,40 +62,65 @@ def cls(op, args):
         return "LDS"
     if op.startswith(("s_cbranch", "s_branch")):
         return "branch"
-    if op.startswith(("s_waitcnt", "s_nop", "s_barrier")):
-        return op.split("_")[1] if op != "s_nop" else "s_nop"
+    if op in ("s_waitcnt", "s_nop", "s_barrier"):
+        return op
     if op.startswith("s_"):
         return "SALU"
     return "other"
 
 
-# main loop: the backward branch behind barrier 3 whose target lies between the last prologue barrier and barrier 1
-addr0 = ins[0][0]
-cands = []
-for k, (a, op, args) in enumerate(ins):
-    if op.startswith(("s_cbranch", "s_branch")) and k > b3:
-        m = re.search(r"(-?\d+)", args)
-        if m:
-            off = int(m.group(1))
-            off = off - 65536 if off > 32767 else off  # (the disassembler prints the 16-bit field unsigned)
-            t = a + 4 + 4 * off
-            if ins[bars[-5]][0] < t <= ins[b1][0]:
-                cands.append((t, k))
-loop_start_addr = min(t for t, _ in cands)
-loop_end = max(k for t, k in cands if t == loop_start_addr)
-ls = next(k for k, (a, _, _) in enumerate(ins) if a >= loop_start_addr)
-phases = [("P1 epoch values (role leaders; cs scan + exp_om | exp, 1/lambda, beta)  -> barrier 1", ls, b1),
-          ("P2 bin terms + row-segmented reduce + tails (every live wave, own role)  -> barrier 2", b1 + 1, b2),
-          ("P3 per-epoch sums, suffix scan (shared) | affine scan (not shared), partial N, D (role leaders)  -> barrier 3", b2 + 1, b3),
-          ("P4 M-step, stop rule (every wave)  -> back edge", b3 + 1, loop_end)]
-print(f"# EM loop of {pat} (gfx950), {ins[loop_end][0] + 4 - loop_start_addr} bytes at +0x{loop_start_addr - addr0:x} .. +0x{ins[loop_end][0] - addr0:x}")
-print("# phase, static instruction counts by class (all paths: both roles' exec-masked halves and the cold paths)")
-for name, lo, hi in phases:
-    c = collections.Counter(cls(op, args) for _, op, args in ins[lo:hi + 1])
-    tot = sum(v for k, v in c.items())
-    print(f"## {name}\n#    {tot} instructions: " + ", ".join(f"{k} {v}" for k, v in sorted(c.items(), key=lambda kv: -kv[1])))
-print()
-for name, lo, hi in phases:
-    print(f"\n######## {name}")
-    for a, op, args in ins[lo:hi + 1]:
-        print(f"  +0x{a - addr0:05x}  {op:28s} {args}")
+kinds = {"C0, C1, C0": "role A (shared) leader", "C1, C1, C0": "role B (not shared) leader",
+         "C0, C0, C1": "role A second bin group, keeps the verdict history", "C1, C0, C0": "role B second bin group",
+         "C0, C1, C1": "role A leader that also keeps the verdict history (one bin group only)", "C0, C0, C0": "role A further bin groups"}
+print(f"# Steady-state EM loops of {pat} (gfx950), built as the Makefile builds em_kernels_ilp.hip")
+# every backward branch whose range holds exactly the three barriers of an iteration is a loop; the COLATE_BOTH(...) line
+# that some instruction of it (the iteration counter) is attributed to tells the kind of wave; of the two loops of a kind
+# the shorter one is the steady-state loop (no log-likelihood)
+found = collections.defaultdict(list)
+for k, (a, op, args, line) in enumerate(ins):
+    if not op.startswith(("s_cbranch", "s_branch")):
+        continue
+    t = target(a, args)
+    if t > a or t not in index:
+        continue
+    k0 = index[t]
+    if sum(1 for x in ins[k0:k] if x[1] == "s_barrier") != 3:
+        continue
+    tags = {m.group(1) for x in ins[k0:k + 1] if x[3] for m in [re.search(r"COLATE_BOTH\(([^)]*)\)", impl_lines[x[3] - 1])] if m}
+    if len(tags) == 1:
+        found[tags.pop()].append((k - k0, k0, k))
+loops = []
+for tag, what in kinds.items():
+    if found.get(tag):
+        _, k0, k1 = min(found[tag])
+        loops.append((tag, what, k0, k1))
+for tag, what, k0, k1 in loops:
+    seg = ins[k0:k1 + 1]
+    c = collections.Counter(cls(op, args) for _, op, args, _ in seg)
+    nb = sum(1 for _, op, _, _ in seg if op.startswith(("s_cbranch", "s_branch")))
+    print(f"## {what}  [COLATE_BOTH({tag})]: {len(seg)} instructions, {seg[-1][0] + 4 - seg[0][0]} bytes at +0x{seg[0][0] - addr0:x}: "
+          + ", ".join(f"{k} {v}" for k, v in sorted(c.items(), key=lambda kv: -kv[1])))
+names = ["P1 epoch values (leaders: cs scan + exp_om | exp, 1/lambda, beta) + rate prefetch  -> barrier 1",
+         "P2 bin terms + row-segmented reduce + tails  -> barrier 2",
+         "P3 per-epoch sums, suffix scan | affine scan, partial N, D (leaders)  -> barrier 3",
+         "P4 M-step  -> back edge"]
+for tag, what, k0, k1 in loops[:2]:  # the two leaders in full
+    print(f"\n\n################ {what}  [COLATE_BOTH({tag})]")
+    seg = ins[k0:k1 + 1]
+    targets = {target(a, args) for a, op, args, _ in ins if op.startswith(("s_cbranch", "s_branch"))}
+    ph = 0
+    print(f"\n######## {names[0]}")
+    prev_uncond = False
+    for a, op, args, line in seg:
+        if a in targets or prev_uncond:
+            print()
+        note = ""
+        if op.startswith(("s_cbranch", "s_branch")):
+            t = target(a, args)
+            inside = seg[0][0] <= t <= seg[-1][0]
+            note = f"   ; -> +0x{t - addr0:05x} ({'backward' if t <= a else 'forward'}{'' if inside else ', out of the loop range'})"
+        print(f"  +0x{a - addr0:05x}  {op:28s} {args}{note}")
+        prev_uncond = op == "s_branch"
+        if op == "s_barrier":
+            ph += 1
+            print(f"\n######## {names[ph]}")
