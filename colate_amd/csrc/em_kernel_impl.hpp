@@ -605,8 +605,17 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     COLATE_STAMP(0)
     // the last epoch absorbs (lambda_{E-1} > 0) in every valid run; the reference asserts it only
     // for bins inside the last epoch (coal_EM.cpp:351)
-    const double lam_last = s_ep[G_LAM * EPAD + E - 1];
-    const bool absorbing = lam_last > 0;
+    // (from this wave's own copy of the rates -- every wave runs the M-step --, not from LDS: the read and its wait were the
+    // first thing behind barrier 1 in role B's waves)
+    bool absorbing = false;
+    {
+      const int cl = (E - 1) >> 6, ll_ = (E - 1) & 63;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        const unsigned long long pos = ballot64(lam_e[c] > 0.0);
+        if (NCH == 1 || c == cl) absorbing = (pos >> ll_) & 1ull;
+      }
+    }
     // ============================================================ P2: bin terms (own bins, own ROLE)
     auto bin_terms = [&](const BinStat& bs, const double lk_own, const bool have_lk) {
       const double a_b = bs.a_b, cnt = bs.cnt, tk = bs.tk, tkn = bs.tkn, dtk = bs.dtk, da = bs.da, db = bs.db;
