@@ -478,6 +478,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   for (int c = 0; c < NCH; c++)  // (only epochs up to the oldest bin with data: the flat ones behind it do not move at all)
     noisy_thr[c] = (double)(c * kWave + lane) <= s_ll[10] ? kNoisyRatio * (dt_e[c] * (kIntegResidue * (s_ll[8] + s_ll[9]))) : 0.0;
   unsigned long long prev_fail = 0;
+  unsigned long long ep_mask[NCH];  // the lanes of each chunk that hold an epoch
+#pragma unroll
+  for (int c = 0; c < NCH; c++) ep_mask[c] = ballot64(ep_on[c]);
   const double thr = 1.0 - p.rel_tol;
   double ll = -__builtin_inf(), prev_ll = -__builtin_inf();  // coal.cpp:3685
   int iter = 0;
@@ -960,6 +963,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     // ---- M-step, coal.cpp:3777-3804
     if (!COLATE_ABL_HAS(14)) {
       double cand[NCH];
+      bool self[NCH];  // this lane's epoch keeps its own quotient (does not copy)
       unsigned long long keep[NCH];  // epochs that do NOT copy their predecessor
       // the copying epochs form a prefix 0..m-1 (they all become 0) unless a bit of `bad` is set: as scalar mask
       // arithmetic, so that one compare and one branch decide
@@ -976,8 +980,11 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           if (qn < p.rate_floor) qn = p.rate_floor;
           cand[c] = (!copy && D_e[c] != 0) ? qn : lam_e[c];
         }
-        keep[c] = ballot64(ep_on[c] && !copy);
-        const unsigned long long cp = ballot64(ep_on[c] && copy);
+        // (the compare's own lane mask and the static mask of the live epoch lanes: scalar arithmetic from here on)
+        const unsigned long long zero_n = __builtin_amdgcn_fcmp(N_e[c], 0.0, 1 /* FCMP_OEQ */);
+        keep[c] = ep_mask[c] & ~zero_n;
+        const unsigned long long cp = ep_mask[c] & zero_n;
+        self[c] = ep_on[c] && !copy;
         bad |= (cp & (cp + 1ull)) | (lower_keep & cp);
         lower_keep |= keep[c] ? ~0ull : 0ull;
       }
@@ -991,7 +998,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       }
       if (__builtin_expect(bad == 0, 1)) {
 #pragma unroll
-        for (int c = 0; c < NCH; c++) lam_e[c] = ((keep[c] >> lane) & 1ull) ? cand[c] : 0.0;
+        for (int c = 0; c < NCH; c++) lam_e[c] = self[c] ? cand[c] : 0.0;
       } else {
         COLATE_COLD();
         // num == 0: take the (already updated) rate of the previous epoch, 0 if there is none
@@ -1009,8 +1016,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
               have_lower = true;
             }
           }
-          const bool self = (keep[c] >> lane) & 1ull;
-          lam_e[c] = ep_on[c] ? (self ? cand[c] : (below ? from_chunk : from_lower)) : 0.0;
+          lam_e[c] = ep_on[c] ? (self[c] ? cand[c] : (below ? from_chunk : from_lower)) : 0.0;
         }
       }
     }
