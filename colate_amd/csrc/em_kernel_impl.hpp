@@ -196,16 +196,17 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput) {
 #else
   (void)erows;
   if (mode != 0) return 0;
-  // measured on MI355X, kernel ms for pads 0..7, final loop code of round 2 (gpurun_out/r02u2/padsweep.txt ->
+  // measured on MI355X, kernel ms for pads 0..7, final loop code of round 2 (gpurun_out/r02y2/padsweep.txt ->
   // profiles/r02_placement.txt).  The pad shifts everything behind it, the loops compiled per kind of wave included.
 #ifdef COLATE_EM_ILP_BUILD
   (void)tput;
-  // latency variant, max-ilp build: E=23 B=100 1.041 1.036 1.043 1.051 1.045 1.051 1.037 1.039 (B=400: 1.254 1.259 1.279 1.269 1.266 1.279 1.271 1.260);
-  // E=122 B=100 1.537 1.553 1.555 1.547 1.537 1.546 1.527 1.547
-  return nch == 1 ? 1 : 6;
+  // latency variant, max-ilp build: E=23 B=100 1.021 1.032 1.024 1.031 1.001 1.022 1.010 1.010 (B=400: 1.220 1.241 1.235 1.232 1.204 1.231 1.215 1.239);
+  // E=122 B=100 1.507 1.506 1.515 1.481 1.504 1.487 1.495 1.509
+  return nch == 1 ? 4 : 3;
 #else
-  if (!tput) return 6;       // latency variant, default build (not picked by colate_em_variant any more; COLATE_EM_VARIANT=latency)
-  return nch == 1 ? 1 : 0;   // throughput variant: E=23 B=4096 6.871 6.827 6.893 6.848 6.886 6.858 6.874 6.824
+  (void)nch;
+  if (!tput) return 6;  // latency variant, default build (not picked by colate_em_variant any more; COLATE_EM_VARIANT=latency)
+  return 0;             // throughput variant: E=23 B=4096 6.638 6.656 6.687 6.665 6.642 6.674 6.654 6.748
 #endif
 #endif
 }
