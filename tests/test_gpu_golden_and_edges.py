@@ -295,7 +295,7 @@ def test_sharded_entry_point_matches_single_launch(ca):
 
 def test_throughput_variant_is_bit_identical(ca, monkeypatch):
     """The kernel has a latency variant (a wave per role and bin group; B up to twice the CU count; built twice:
-    max-ilp scheduling for B <= #CUs, default scheduling = one more resident wave per SIMD beyond) and a
+    max-ilp scheduling -- the one the library picks -- and default scheduling, kept for A/B runs) and a
     throughput variant (two waves per replicate walking through the bin groups; larger B, or more than 128 epochs).  Same phases, same
     arithmetic: rates, log-likelihoods, iteration counts and flags agree bit for bit, so results do not depend
     on the batch size a replicate happens to be run in."""
