@@ -222,6 +222,30 @@ def test_edge_cases(ca):
     assert (it == it0).all() and _rel(r, r0)[m].max() < RATE_RTOL
 
 
+@pytest.mark.parametrize("bins", ["3,7,0.2", "2,7.95,0.05"])
+def test_iteration_limits_around_the_loop_hand_overs(ca, bins):
+    """The kernel runs the iterations before min_iter, those from min_iter on and (for some waves) all of them in
+    different loops (em_kernel_impl.hpp, COLATE_BOTH): every combination of the two limits that moves the hand-over
+    points -- no steady iteration at all, a cap below / at / just above min_iter, a stop rule that fires at once --
+    gives the oracle's iteration count, log-likelihood and rates."""
+    from colate_amd import workloads
+
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins(bins)
+    csh, cns = workloads.bootstrap_tables(grid, 3, nb=9, scale=1.0, seed=5)
+    csh[1, 70:] = 0.0
+    cns[1, 70:] = 0.0  # a replicate whose data fit one bin group (its leader keeps the verdict's history itself)
+    for max_iter, min_iter in ((1, 1000), (2, 1000), (3, 1), (40, 0), (40, 39), (40, 40), (41, 40), (300, 5), (1200, 1000)):
+        kw = dict(max_iter=max_iter, min_iter=min_iter, rel_tol=1e-3 if min_iter < 10 else 1e-7)
+        r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep, **kw)
+        r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep, **kw)
+        assert (it0 == it1).all(), (kw, it0, it1)
+        assert (fl0 == ca.status_flags(fl1)).all(), (kw, fl0, fl1)
+        assert np.allclose(ll1, ll0, rtol=1e-11, atol=0), kw
+        mask = ol.stable_mask(grid, csh, cns, ep, r0, **kw)
+        assert mask.mean() > 0.8 and _rel(r1, r0)[mask].max() < RATE_RTOL, (kw, _rel(r1, r0)[mask].max())
+
+
 def test_properties_at_baseline_sizes(ca):
     """Size-independent properties at configs[2]/[4] scale (1000 and 2000 replicates in one launch)."""
     from colate_amd import workloads
