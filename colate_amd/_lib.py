@@ -32,6 +32,7 @@ SIGNATURES = {
     "colate_last_error": (c_char_p, []),
     "colate_device_count": (c_int, []),
     "colate_set_device": (c_int, [c_int]),
+    "colate_warm_up": (c_int, [c_int]),
     "colate_em_kernel_variant": (c_int, [c_int, c_int]),
     "colate_em_batch": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -248,6 +248,14 @@ int colate_set_device(int ordinal) {
   return COLATE_OK;
 }
 
+int colate_warm_up(int ordinal) {
+  // creates the HIP context of the device (a few hundred ms in a fresh process): a host that still has input files to
+  // parse calls this from a second thread first (mut_driver.cpp)
+  HIP_TRY(hipSetDevice(ordinal));
+  HIP_TRY(hipFree(nullptr));
+  return COLATE_OK;
+}
+
 int colate_em_kernel_variant(int B, int E) {
   if (B < 0 || E < 1 || E > COLATE_EM_MAX_E) return fail(COLATE_EINVAL, "bad sizes B=%d E=%d", B, E);
   if (int rc = ensure_device()) return rc;

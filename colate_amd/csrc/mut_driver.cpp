@@ -26,6 +26,7 @@
 #include <random>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "colate_amd.h"
@@ -515,6 +516,17 @@ int run_mut(const Options& opt) {
   }
   std::cerr << "---------------------------------------------------------" << std::endl;
   std::cerr << "Calculating coalescence rates for (ancient) samples.." << std::endl;
+
+  // One process, one GPU: create the HIP context on a second thread while this one parses the input files (a fresh
+  // process pays a few hundred ms for it; end to end 0.63 -> see profiles/r02/bench/e2e.txt).  Not with --ranks (every
+  // rank picks its own device after the fork) or --devices (several contexts), not when no device is needed.
+  struct Warm {
+    std::thread t;
+    ~Warm() {
+      if (t.joinable()) t.join();
+    }
+  } warm;
+  if (!g_rank.ranked && !opt.has("devices") && !opt.has("counts_only")) warm.t = std::thread([] { (void)colate_warm_up(0); });
 
   double target_age = 0, ref_age = 0;
   try {

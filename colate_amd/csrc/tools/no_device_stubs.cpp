@@ -30,6 +30,7 @@ const char* colate_version(void) { return "colate_amd host sanitizer build (no d
 const char* colate_last_error(void) { return colate::g_err.c_str(); }
 int colate_device_count(void) { return nodev(); }
 int colate_set_device(int) { return nodev(); }
+int colate_warm_up(int) { return nodev(); }
 int colate_em_batch(int, int, int, const double*, const double*, const double*, const double*, const double*, int, int,
                     double, double, double*, int*, double*, int*) { return nodev(); }
 int colate_em_batch_rows(int, int, int, const double*, const double*, const double*, const double*, const double*, int, int,

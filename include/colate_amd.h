@@ -68,6 +68,9 @@ const char* colate_version(void);
 const char* colate_last_error(void);
 int colate_device_count(void);       /* >= 0, or COLATE_ENODEVICE */
 int colate_set_device(int ordinal);  /* device used by the calling thread's later calls */
+/* Creates the device's HIP context now (from any thread) instead of inside the first compute call: lets a host overlap
+ * the few hundred ms a fresh process pays for it with its own input parsing.  No reference counterpart (CPU code). */
+int colate_warm_up(int ordinal);
 /* Diagnostic: which build of the EM kernel a batch of this shape runs on the current device
  * (0 latency/max-ilp, 1 latency/default scheduler, 2 throughput), or a negative code. */
 int colate_em_kernel_variant(int B, int E);
