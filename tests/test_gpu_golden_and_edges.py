@@ -440,6 +440,34 @@ def test_flags(ca):
     assert (fl & ca.FLAG_NAN).all()
 
 
+@pytest.mark.parametrize("bins", ["3,7,0.2", "2,7.95,0.05"])
+def test_zero_starting_rates_and_failing_normalisers(ca, bins):
+    """Starting rates of 0 (a --coal file may hold them): a zero rate is a fixed point of the M-step where nothing older
+    coalesces into the epoch, the last epoch stops absorbing (the kernel's cold path), and shared bins inside a run of
+    leading zero-rate epochs have a normaliser of 0 -- the reference drops them (coal_EM.cpp:288-292), the kernel
+    publishes them to its role leader every iteration.  Same iterations, flags, log-likelihood and rates as the oracle."""
+    from colate_amd import workloads
+
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins(bins)
+    E = ep.size
+    csh, cns = workloads.bootstrap_tables(grid, 2, nb=9, scale=1.0, seed=5)
+    third = E // 3
+    for zero in ([0], [0, 1, 2], list(range(third)), [third], list(range(third, third + 4)), [E - 1], [0, E - 1], [E - 2, E - 1]):
+        init = np.full(E, 1.0 / 20000.0)
+        init[zero] = 0.0
+        kw = dict(init=init, max_iter=60, min_iter=10)
+        r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep, **kw)
+        if (fl0 & 3).any():  # (the reference itself aborts on this start)
+            continue
+        r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep, init_rates=init, max_iter=60, min_iter=10)
+        assert (it0 == it1).all() and (fl0 == ca.status_flags(fl1)).all(), (zero, it0, it1, fl0, fl1)
+        assert np.allclose(ll1, ll0, rtol=1e-11, atol=0), (zero, ll0, ll1)
+        assert ((r0 == 0) == (r1 == 0)).all(), zero
+        mask = ol.stable_mask(grid, csh, cns, ep, r0, **kw)
+        assert mask.mean() > 0.7 and _rel(r1, r0)[mask].max() < RATE_RTOL, (zero, mask.mean(), _rel(r1, r0)[mask].max())
+
+
 def test_device_bootstrap_bit_identical_to_host(ca):
     """Block bootstrap on the GPU (weighted block sums + F redistribution, coal.cpp:3358-3441) against
     the host path, same std::mt19937 weights: bit-identical tables, then EM straight from HBM."""
