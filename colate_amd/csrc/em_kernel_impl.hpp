@@ -301,6 +301,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       if (csh > 0 || cns > 0) {
         atomicMin(&s_misc[0], t);
         atomicMax(&s_misc[1], t + 1);
+        atomicAdd(&s_misc[3], (csh > 0 ? 1 : 0) + (cns > 0 ? 1 : 0));  // (bin, kind) pairs the reference evaluates: for the epilogue
       }
     }
     s_kb[t] = kb;
@@ -1134,6 +1135,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     // residue and the rate sits on the floor, the floor is what every build prints.  The count of such trailing epochs
     // goes out in the high bits of out_flags (COLATE_FLAG_UNRESOLVED, COLATE_UNRESOLVED_EPOCHS()).
     int first_bad = E;
+    const int n_evals = s_misc[3];  // (read before this wave stores the verdict there)
+    constexpr int kMinEvals = 32;
 #pragma unroll
     for (int c = NCH - 1; c >= 0; c--) {
       const int e = c * kWave + lane;
@@ -1146,7 +1149,6 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       // reach zero (the reference's exp(A_e - Z_b) per bin, the kernel's W_e RS_e and q_e T_e chains).  So an epoch whose
       // numerator was ever within a factor 1e-280 of that edge while not being a structural zero (0 in every iteration,
       // like epoch 0) is not reproducible.
-      (void)Nfin;
       const bool snapshot = ((ever_tiny[c] >> lane) & 1ull) && ((ever_nonzero[c] >> lane) & 1ull);
       // An epoch that starts after the oldest bin with data: every contribution to its statistics has num/denom equal to
       // the current rate (the likelihood does not depend on it), so the EM leaves it where it is -- normally at its starting
@@ -1160,8 +1162,15 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       // own (measured: sparse tables, the last epoch with data overshoots x4 on the reference, its survival underflows and
       // the flat epoch behind it ends as a copy, while the exact sums never come near; profiles/parity/sweep2_sparse_*).
       const bool path_dependent = (double)e > s_ll[10] && ever_noisy != 0;
+      // "Denominator nothing but residue, rate on the floor" is what every build prints only if the reference's own residue
+      // cannot be so much smaller than the modelled one that its quotient leaves the floor: the model is an average over
+      // the (bin, kind) pairs it evaluates -- with a handful of them the actual residue may be 0 (tools/fuzz_parity.py
+      // found tables of 5 mutations where the reference prints 2e-4 and the kernel the floor) -- and the numerator must
+      // stay below floor x (exact part + a fifth of the modelled residue).
+      const bool deep_floor = lam_e[c] <= p.rate_floor && D < 3.0 * eta && n_evals >= kMinEvals &&
+                              Nfin <= p.rate_floor * (D - 0.8 * eta);
       const bool resolved = !ep_on[c] || (!snapshot && !drifted && !path_dependent &&
-                            (D >= kResolvedRatio * eta || (lam_e[c] <= p.rate_floor && D < 3.0 * eta)));
+                            (D >= kResolvedRatio * eta || deep_floor));
       const unsigned long long bad = ballot64(!resolved);
       if (bad) first_bad = c * kWave + __builtin_ctzll(bad);
     }

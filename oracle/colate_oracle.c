@@ -267,6 +267,9 @@ double oracle_estep(int E, int A, const double* epochs, const double* rates, con
                         : oracle_em_notshared(E, epochs, rates, A_ep, B_ep, age_grid[bin], num,
                                               denom);
       ll += count * logl;
+      /* coal_EM.cpp:351: for a not-shared count inside the last epoch the reference asserts rate > 0 (it aborts);
+       * reported like the other aborts (coal.cpp:3711) */
+      if (kind == 1 && !(age_grid[bin] < epochs[E - 1]) && !(rates[E - 1] > 0)) *flags |= ORACLE_FLAG_NAN;
       for (int e = 0; e < E; e++) {
         if (isnan(num[e]) || isnan(denom[e])) *flags |= ORACLE_FLAG_NAN;
         if (num[e] < 0.0 || denom[e] < 0.0) *flags |= ORACLE_FLAG_NEG;

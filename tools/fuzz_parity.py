@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the EM kernel against the oracle (GPU box): random epoch grids (2 .. 256 epochs: every
+instantiation and both layouts), random age grids (1 .. 256 bins: 1 .. 4 bin groups, runs of bins per epoch of any length:
+the two-slot loops and the general loop), dense and sparse count tables, empty ranges, random starting rates (zeros
+included), random iteration limits.  Per case: iteration counts, status flags, log-likelihood and the rates on the epochs
+the checker finds stable (tests/oracle_lib.stable_mask) must agree; on the epochs the kernel calls resolved too.
+
+    gpurun -- 'python3 tools/fuzz_parity.py 300 > gpurun_out/fuzz.txt'      (profiles/parity/fuzz.txt)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import colate_amd  # noqa: E402
+import oracle_lib as ol  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1  # replay one case, verbosely
+bad = 0
+skipped = 0
+degenerate = 0
+soft_checker = 0
+soft_kernel = 0
+off_by_one = 0
+worst = 0.0
+t_start = time.time()
+for case in range(n_cases):
+    if only >= 0 and case != only:
+        continue
+    rng = np.random.default_rng(seed0 * 100003 + case)
+    # epoch grids of the CLI's form: 0, then log-spaced starts (--bins lo,hi,step in log10 years / 28, or a Relate .coal:
+    # the same shape), last epoch far out.  (Arbitrary grids -- epochs two generations wide at random places -- put the
+    # reference's beta_e = (t + 1/lambda) - (t' + 1/lambda) q into catastrophic cancellation, lambda dt < 1e-6: its own
+    # output is rounding noise there and no claim is made)
+    E = int(rng.choice([2, 3, 5, 16, 17, 23, 31, 32, 33, 43, 64, 65, 100, 128, 129, 200, 256]))
+    A = int(rng.choice([1, 2, 7, 40, 64, 65, 100, 128, 129, 185, 200, 256]))
+    lo10 = rng.uniform(2.0, 3.5)
+    hi10 = rng.uniform(max(lo10 + 0.5, 5.0), 8.0)
+    inner = 10 ** np.linspace(lo10, hi10, E - 2) / 28.0 if E > 2 else np.zeros(0)
+    tmax = 10 ** hi10 / 28.0
+    ep = np.concatenate([[0.0], inner, [10 ** (hi10 + rng.uniform(0.05, 1.5)) / 28.0]])[:E]
+    ep = np.maximum.accumulate(ep)
+    if rng.uniform() < 0.6:
+        grid = ol.age_grid()[:A] if A <= 185 else np.concatenate([ol.age_grid(), ol.age_grid()[-1] * np.exp(np.arange(1, A - 184) / 10.0)])
+    else:
+        grid = np.sort(np.exp(rng.uniform(np.log(1.0), np.log(tmax * 2), A)))
+        if rng.uniform() < 0.3 and A > 4 and E > 3:
+            grid[A // 2] = ep[E // 2]  # an age exactly on an epoch start
+            grid = np.sort(grid)
+    B = int(rng.choice([1, 2, 3]))
+    dens = rng.choice([0.05, 0.5, 1.0])
+    scale = 10 ** rng.uniform(-0.5, 3)
+    p_sh = 1 - np.exp(-grid / 10 ** rng.uniform(3, 5))
+    tot = rng.poisson(scale, (B, A)) * (rng.uniform(size=(B, A)) < dens)
+    lo, hi = sorted(rng.integers(0, A + 1, 2))
+    if rng.uniform() < 0.4:
+        tot[:, :lo] = 0
+        tot[:, hi:] = 0
+    csh = rng.binomial(tot, np.clip(0.8 * p_sh, 0, 1)[None, :]).astype(float)
+    cns = (tot - csh).astype(float)
+    if rng.uniform() < 0.3:
+        csh *= rng.uniform(0.1, 3.0)  # non-integer counts (bootstrap weights)
+        cns *= rng.uniform(0.1, 3.0)
+    init = None
+    if rng.uniform() < 0.5:
+        init = np.exp(rng.uniform(np.log(1e-7), np.log(1e-2), E))
+        if rng.uniform() < 0.4:
+            init[rng.integers(0, E, rng.integers(1, 4))] = 0.0
+    max_iter = int(rng.choice([1, 2, 30, 150, 400]))
+    min_iter = int(rng.choice([0, 1, 25, 100, 1000]))
+    kw = dict(max_iter=max_iter, min_iter=min_iter, rel_tol=float(rng.choice([1e-7, 1e-4])))
+    r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep, init=init, **kw)
+    ok = (fl0 & 3) == 0  # replicates the reference itself runs through
+    # A log-likelihood that is exactly 0 (all data at age 0 with not-shared counts only): the reference's own value is
+    # the rounding noise of its log-domain sums (+-1e-16, changing sign from one iteration to the next) and its stop rule
+    # fires on the ratio of two such numbers; the kernel's sums give 0 and 0/0 never stops.  Not comparable.
+    noise_ll = np.abs(ll0) < 1e-12 * np.maximum((csh + cns).sum(axis=1), 1e-300)
+    degenerate += int((ok & noise_ll).sum())
+    ok &= ~noise_ll
+    if not ok.any():
+        skipped += 1
+        continue
+    r1, it1, ll1, fl1 = colate_amd.em_batch(grid, csh, cns, ep, init_rates=init, **kw)
+    if only >= 0:
+        np.set_printoptions(precision=17, linewidth=200)
+        print("epochs", ep, "\ngrid", grid, "\ncsh", csh, "\ncns", cns, "\ninit", init)
+        print("oracle: iterations", it0, "flags", fl0, "ll", ll0, "\nkernel: iterations", it1, "flags", fl1, "ll", ll1)
+        for v in ("latency-ilp", "latency", "throughput"):
+            os.environ["COLATE_EM_VARIANT"] = v
+            print(v, [x.tolist() for x in colate_amd.em_batch(grid, csh, cns, ep, init_rates=init, **kw)[1:3]])
+        del os.environ["COLATE_EM_VARIANT"]
+        for mi in (1, 2, 3, 4, 5, 10):
+            a = ol.em_batch(grid, csh, cns, ep, init=init, max_iter=mi, min_iter=kw["min_iter"], rel_tol=kw["rel_tol"])
+            b = colate_amd.em_batch(grid, csh, cns, ep, init_rates=init, max_iter=mi, min_iter=kw["min_iter"], rel_tol=kw["rel_tol"])
+            print("max_iter", mi, "oracle it/ll", a[1].tolist(), a[2].tolist(), "kernel it/ll", b[1].tolist(), b[2].tolist())
+    st = colate_amd.status_flags(fl1)
+    mask = ol.stable_mask(grid, csh, cns, ep, r0, init=init, **kw) & ok[:, None]
+    unres = colate_amd.unresolved_epochs(fl1)
+    keep = (np.arange(E)[None, :] < (E - unres)[:, None]) & ok[:, None]
+    rel = np.abs(r1 - r0) / np.maximum(np.abs(r0), 1e-300)
+    with np.errstate(all="ignore"):
+        ll_ok = np.all(np.isclose(ll1[ok], ll0[ok], rtol=1e-8, atol=1e-12) | (np.isnan(ll1[ok]) & np.isnan(ll0[ok])) | (ll1[ok] == ll0[ok]))
+    problems = []
+    if not (it0[ok] == it1[ok]).all():
+        if (np.abs(it0[ok] - it1[ok]) <= 1).all():  # the stop rule compares ll / ll_prev with 1 - rel_tol: a 1e-13 difference can move the crossing by one
+            off_by_one += 1
+        else:
+            problems.append(f"iterations {it0[ok].tolist()} vs {it1[ok].tolist()}")
+    if not (fl0[ok] == st[ok]).all():
+        problems.append(f"flags {fl0[ok].tolist()} vs {st[ok].tolist()}")
+    if not ll_ok:
+        problems.append(f"loglik {ll0[ok].tolist()} vs {ll1[ok].tolist()}")
+    m1 = float(rel[mask].max(initial=0.0))
+    m2 = float(rel[keep].max(initial=0.0))
+    m3 = float(rel[mask & keep].max(initial=0.0))
+    if m3 > 1e-6:
+        problems.append(f"rates differ by {m3:.2e} on an epoch that is checker-stable AND kernel-resolved")
+    notes = []
+    if m1 > 1e-6 and m3 <= 1e-6:
+        notes.append(f"(checker-stable but flagged by the kernel: differs by {m1:.2e})")
+        soft_checker += 1
+    if m2 > 1e-6 and m3 <= 1e-6:
+        notes.append(f"(kernel-resolved but unstable for the checker: differs by {m2:.2e})")
+        soft_kernel += 1
+    worst = max(worst, m3)
+    if only >= 0:
+        b = int(np.argmax(np.where(mask | keep, rel, 0).max(axis=1)))
+        print("replicate", b, "epoch: start, oracle rate, kernel rate, rel diff, checker-stable, kernel-resolved")
+        for e in range(E):
+            print(f"  {e:3d} {ep[e]:12.5g} {r0[b, e]:.17g} {r1[b, e]:.17g} {rel[b, e]:.2e} {bool(mask[b, e])} {bool(keep[b, e])}")
+        N0, D0, l0, f0 = ol.estep(ep, init if init is not None else np.full(E, 1.0 / 20000.0), grid, csh[b], cns[b])
+        num, den, l1, f1 = colate_amd.em_estep(grid, csh[b:b + 1], cns[b:b + 1], ep, (init if init is not None else np.full(E, 1.0 / 20000.0))[None, :])
+        print("first E-step: epoch, oracle N, kernel N, oracle D, kernel D")
+        for e in range(E):
+            print(f"  {e:3d} {N0[e]:.17g} {num[0, e]:.17g} {D0[e]:.17g} {den[0, e]:.17g}")
+    tag = "FAIL" if problems else "ok"
+    if problems:
+        bad += 1
+    print(f"{tag} case {case}: E={E} A={A} B={B} live bins {int(((csh + cns) > 0).any(axis=0).sum())} init={'given' if init is not None else 'default'} "
+          f"{kw} iterations {it0.tolist()} oracle flags {fl0.tolist()} stable {mask.mean():.2f} resolved {keep.mean():.2f} "
+          f"max rel on both-claimed {m3:.1e} " + "; ".join(problems + notes), flush=True)
+print(f"{n_cases} cases, {skipped} skipped (the reference aborts on all replicates, or its log-likelihood is rounding noise: {degenerate} replicates), {bad} failures; {off_by_one} cases with an iteration count off by one (rates then compared after different iteration counts); {soft_kernel} cases where an epoch the kernel calls resolved but the checker finds unstable differs by more than 1e-6, {soft_checker} the other way round; worst relative difference on epochs both claim "
+      f"{worst:.2e}, {time.time() - t_start:.0f} s")
+sys.exit(1 if bad else 0)
