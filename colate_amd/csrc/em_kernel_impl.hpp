@@ -196,17 +196,17 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput) {
 #else
   (void)erows;
   if (mode != 0) return 0;
-  // measured on MI355X, kernel ms for pads 0..7, final loop code of round 2 (gpurun_out/r02y2/padsweep.txt ->
+  // measured on MI355X, kernel ms for pads 0..7, final loop code of round 2 (gpurun_out/r02zz/padsweep.txt ->
   // profiles/r02_placement.txt).  The pad shifts everything behind it, the loops compiled per kind of wave included.
 #ifdef COLATE_EM_ILP_BUILD
   (void)tput;
-  // latency variant, max-ilp build: E=23 B=100 1.021 1.032 1.024 1.031 1.001 1.022 1.010 1.010 (B=400: 1.220 1.241 1.235 1.232 1.204 1.231 1.215 1.239);
-  // E=122 B=100 1.507 1.506 1.515 1.481 1.504 1.487 1.495 1.509
-  return nch == 1 ? 4 : 3;
+  // latency variant, max-ilp build: E=23 B=100 1.019 1.031 1.023 1.030 0.998 1.021 1.010 1.011 (B=400: 1.224 1.245 1.236 1.235 1.208 1.230 1.219 1.235);
+  // E=122 B=100 1.490 1.504 1.507 1.503 1.521 1.491 1.505 1.481
+  return nch == 1 ? 4 : 7;
 #else
   (void)nch;
   if (!tput) return 6;  // latency variant, default build (not picked by colate_em_variant any more; COLATE_EM_VARIANT=latency)
-  return 0;             // throughput variant: E=23 B=4096 6.638 6.656 6.687 6.665 6.642 6.674 6.654 6.748
+  return 4;             // throughput variant: E=23 B=4096 6.680 6.622 6.657 6.640 6.617 6.677 6.648 6.643
 #endif
 #endif
 }
