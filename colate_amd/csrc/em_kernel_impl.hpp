@@ -1063,6 +1063,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       break;                                                  \
     }                                                         \
   }
+#ifndef COLATE_LL_MAX_NCH
+#define COLATE_LL_MAX_NCH 1  // (epoch chunks up to which the log-likelihood-phase loops are compiled, see below)
+#endif
 #ifdef COLATE_NO_LL_LOOPS  // (A/B switch: the iterations from min_iter on in the general loop)
 #define COLATE_BOTH(R, L, T)                                  \
   {                                                           \
@@ -1072,7 +1075,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #define COLATE_BOTH(R, L, T)                                  \
   {                                                           \
     if (iter < n_steady) COLATE_STEADY(R, L, T);              \
-    if constexpr (NCH == 1) COLATE_STEADY_LL(R, L, T)         \
+    if constexpr (NCH <= COLATE_LL_MAX_NCH) COLATE_STEADY_LL(R, L, T) \
   }
 #endif
     if (!(any_more_rows || third_row)) {

@@ -24,7 +24,7 @@ impl = os.path.join(ROOT, "colate_amd", "csrc", "em_kernel_impl.hpp")
 elf = "/tmp/isa_listing.elf"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-I{ROOT}/include",
                        "--offload-arch=gfx950", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-force-precise-rotation-cost=true",
-                       "-gline-tables-only", "--cuda-device-only", "-c", "--no-gpu-bundle-output", src, "-o", elf], stderr=subprocess.DEVNULL)
+                       "-gline-tables-only", *os.environ.get("EXTRA_FLAGS", "").split(), "--cuda-device-only", "-c", "--no-gpu-bundle-output", src, "-o", elf], stderr=subprocess.DEVNULL)
 dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "-l", elf], text=True).split("\n")
 start = [i for i, l in enumerate(dis) if re.match(r"^[0-9a-f]+ <.*" + re.escape(pat) + r".*>:$", l)][0]
 end = next(i for i in range(start + 1, len(dis)) if re.match(r"^[0-9a-f]+ <.*>:$", dis[i]))
