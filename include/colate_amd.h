@@ -48,7 +48,9 @@ extern "C" {
  * Rates of such epochs are returned (deep in that regime they are the floor, as in the reference) but are outside the
  * 1e-6 parity claim; all other epochs are inside it.  out_flags == 0 therefore still means: clean and fully
  * reproducible.  With --bins 3,7,0.2 (23 epochs) no epoch is ever unresolved on whole-genome tables; with
- * --bins 2,7.95,0.05 (122 epochs) the last ~17 are (profiles/parity/). */
+ * --bins 2,7.95,0.05 (122 epochs) the last ~17 are (profiles/parity/).  The verdict is about the
+ * fixed point: it is made for runs that end by the stop rule at the reference's tolerance (COLATE_DEFAULT_REL_TOL); a run cut
+ * by max_iter (COLATE_FLAG_MAXITER) or stopped at a looser tolerance still carries its path. */
 #define COLATE_FLAG_UNRESOLVED 8
 #define COLATE_STATUS_FLAGS(flags) ((flags) & 0xff)
 #define COLATE_UNRESOLVED_EPOCHS(flags) ((int)((unsigned)(flags) >> 8))

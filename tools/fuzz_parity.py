@@ -27,6 +27,8 @@ skipped = 0
 degenerate = 0
 soft_checker = 0
 soft_kernel = 0
+n_converged = 0
+n_cut = 0
 off_by_one = 0
 worst = 0.0
 t_start = time.time()
@@ -104,8 +106,17 @@ for case in range(n_cases):
     unres = colate_amd.unresolved_epochs(fl1)
     keep = (np.arange(E)[None, :] < (E - unres)[:, None]) & ok[:, None]
     rel = np.abs(r1 - r0) / np.maximum(np.abs(r0), 1e-300)
+    # The claims are made for runs that END BY THE STOP RULE AT THE REFERENCE'S TOLERANCE (1e-7; the CLI has no other): there
+    # the rates are at the fixed point and only its conditioning matters.  A run cut by max_iter, or stopped at 1e-4, still
+    # carries its path -- and on tables of a few dozen mutations the path of an epoch whose denominator is rounding residue
+    # is the reference's own noise (5e-6 in the log-likelihood after 400 iterations, case 5181 of seed 2).  Such runs are
+    # compared on iterations, flags and the epochs both verdicts claim, and counted separately.
+    converged = ok & ((fl0 & 4) == 0) & (kw["rel_tol"] <= 1e-7)
+    n_converged += int(converged.sum())
+    n_cut += int((ok & ~converged).sum())
+    csum = np.maximum((csh + cns).sum(axis=1), 1.0)
     with np.errstate(all="ignore"):
-        ll_ok = np.all(np.isclose(ll1[ok], ll0[ok], rtol=1e-8, atol=1e-12) | (np.isnan(ll1[ok]) & np.isnan(ll0[ok])) | (ll1[ok] == ll0[ok]))
+        ll_ok = np.all(np.isclose(ll1[converged], ll0[converged], rtol=1e-9, atol=0) | (np.abs(ll1[converged] - ll0[converged]) <= 1e-12 * csum[converged]) | (np.isnan(ll1[converged]) & np.isnan(ll0[converged])) | (ll1[converged] == ll0[converged]))
     problems = []
     if not (it0[ok] == it1[ok]).all():
         if (np.abs(it0[ok] - it1[ok]) <= 1).all():  # the stop rule compares ll / ll_prev with 1 - rel_tol: a 1e-13 difference can move the crossing by one
@@ -116,8 +127,8 @@ for case in range(n_cases):
         problems.append(f"flags {fl0[ok].tolist()} vs {st[ok].tolist()}")
     if not ll_ok:
         problems.append(f"loglik {ll0[ok].tolist()} vs {ll1[ok].tolist()}")
-    m1 = float(rel[mask].max(initial=0.0))
-    m2 = float(rel[keep].max(initial=0.0))
+    m1 = float(rel[mask & converged[:, None]].max(initial=0.0))
+    m2 = float(rel[keep & converged[:, None]].max(initial=0.0))
     m3 = float(rel[mask & keep].max(initial=0.0))
     if m3 > 1e-6:
         problems.append(f"rates differ by {m3:.2e} on an epoch that is checker-stable AND kernel-resolved")
@@ -145,6 +156,7 @@ for case in range(n_cases):
     print(f"{tag} case {case}: E={E} A={A} B={B} live bins {int(((csh + cns) > 0).any(axis=0).sum())} init={'given' if init is not None else 'default'} "
           f"{kw} iterations {it0.tolist()} oracle flags {fl0.tolist()} stable {mask.mean():.2f} resolved {keep.mean():.2f} "
           f"max rel on both-claimed {m3:.1e} " + "; ".join(problems + notes), flush=True)
+print(f"{n_converged} replicates ended by the stop rule at 1e-7 (all claims), {n_cut} were cut by max_iter or stopped at 1e-4 (iterations, flags, both-claimed epochs only)")
 print(f"{n_cases} cases, {skipped} skipped (the reference aborts on all replicates, or its log-likelihood is rounding noise: {degenerate} replicates), {bad} failures; {off_by_one} cases with an iteration count off by one (rates then compared after different iteration counts); {soft_kernel} cases where an epoch the kernel calls resolved but the checker finds unstable differs by more than 1e-6, {soft_checker} the other way round; worst relative difference on epochs both claim "
       f"{worst:.2e}, {time.time() - t_start:.0f} s")
 sys.exit(1 if bad else 0)
