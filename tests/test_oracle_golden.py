@@ -60,3 +60,21 @@ def test_logsumexp_special_values():
     assert ol.O.oracle_logminusexp(-2.0, -2.0) == -inf
     assert ol.O.oracle_logminusexp(-1.0, -inf) == -1.0
     assert abs(ol.O.oracle_logsumexp(-1.0, -1.0) - (-1.0 + np.log(2.0))) < 1e-15
+
+
+def test_oracle_reports_the_last_epoch_assert():
+    """coal_EM.cpp:351: for a not-shared count inside the last epoch the reference asserts rate > 0 (it aborts); the
+    oracle reports it with the NaN flag, like the aborts at coal.cpp:3711 -- what the kernel does (tests/test_gpu_*::test_flags)."""
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins("3,7,0.2")
+    rates = np.full(ep.size, 1.0 / 20000.0)
+    rates[-1] = 0.0
+    csh, cns = np.zeros(grid.size), np.zeros(grid.size)
+    cns[grid >= ep[-1]] = 2.0  # not-shared counts beyond the start of the last epoch
+    assert (grid >= ep[-1]).any()
+    N, D, ll, fl = ol.estep(ep, rates, grid, csh, cns)
+    assert fl & 1
+    cns[:] = 0.0
+    cns[100] = 2.0  # the same zero rate is harmless for a bin in an earlier epoch
+    N, D, ll, fl = ol.estep(ep, rates, grid, csh, cns)
+    assert fl == 0
