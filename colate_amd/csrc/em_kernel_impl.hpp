@@ -1104,6 +1104,17 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #undef COLATE_BOTH
 #undef COLATE_STEADY_LL
 #undef COLATE_STEADY
+    // ... and where the per-kind loops of that phase are not built (more than 64 epochs), one loop compiled for "log-likelihood
+    // needed" only: no cost for the steady loops, 2.20 -> 2.08 us per iteration at E = 122
+    if constexpr (NCH > COLATE_LL_MAX_NCH) if (!(any_more_rows || third_row)) {
+      using CR = std::integral_constant<int, -1>;
+      for (; iter < max_iter; iter++) {
+        if (iteration(CR{}, CR{}, C1{}, CR{})) {
+          stopped = true;
+          break;
+        }
+      }
+    }
   }
   for (; !stopped && iter < max_iter; iter++) {
     using CR = std::integral_constant<int, -1>;
