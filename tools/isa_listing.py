@@ -19,11 +19,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pat = sys.argv[1] if len(sys.argv) > 1 else "em_kernelILi0ELi1ELi2ELb0"
-src = os.path.join(ROOT, "colate_amd", "csrc", "em_kernels_ilp.hip")
+src = os.path.join(ROOT, "colate_amd", "csrc", os.environ.get("SRC", "em_kernels_ilp.hip"))  # SRC=em_kernels.hip NOILP=1: the default-scheduler builds (throughput variant)
 impl = os.path.join(ROOT, "colate_amd", "csrc", "em_kernel_impl.hpp")
 elf = "/tmp/isa_listing.elf"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-I{ROOT}/include",
-                       "--offload-arch=gfx950", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-force-precise-rotation-cost=true",
+                       "--offload-arch=gfx950", *([] if os.environ.get("NOILP") else ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]), "-mllvm", "-force-precise-rotation-cost=true",
                        "-gline-tables-only", *os.environ.get("EXTRA_FLAGS", "").split(), "--cuda-device-only", "-c", "--no-gpu-bundle-output", src, "-o", elf], stderr=subprocess.DEVNULL)
 dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "-l", elf], text=True).split("\n")
 start = [i for i, l in enumerate(dis) if re.match(r"^[0-9a-f]+ <.*" + re.escape(pat) + r".*>:$", l)][0]
