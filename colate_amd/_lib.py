@@ -33,6 +33,7 @@ SIGNATURES = {
     "colate_device_count": (c_int, []),
     "colate_set_device": (c_int, [c_int]),
     "colate_warm_up": (c_int, [c_int]),
+    "colate_device_touched": (c_int, []),
     "colate_em_kernel_variant": (c_int, [c_int, c_int]),
     "colate_em_batch": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),

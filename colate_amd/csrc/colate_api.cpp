@@ -3,9 +3,13 @@
 // buffers for the host-pointer variants, kernel launch.  No CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -50,7 +54,11 @@ static int check_sizes(int B, int E, int A) {
   return COLATE_OK;
 }
 
-static int ensure_device() {
+static std::atomic<int> g_device_touched{0};
+void mark_device_touched() { g_device_touched.store(1, std::memory_order_relaxed); }
+
+int ensure_device() {
+  mark_device_touched();
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
@@ -60,7 +68,7 @@ static int ensure_device() {
 }
 
 // grids that the kernel's contiguous-segment logic relies on
-static int check_grids(int E, int A, const double* age_grid, const double* epochs) {
+int check_grids(int E, int A, const double* age_grid, const double* epochs) {
   for (int b = 0; b < A; b++) {
     if (!(age_grid[b] >= 0.0) || (b > 0 && age_grid[b] < age_grid[b - 1]))
       return fail(COLATE_EINVAL, "age_grid must be non-negative and non-decreasing (index %d)", b);
@@ -101,8 +109,10 @@ struct DevBuf {
 // One device buffer, one pinned host staging buffer and one stream per calling thread, grown on demand and
 // kept between calls (colate_release_workspace frees them): a call costs one staged host-to-device copy,
 // the launch(es), one device-to-host copy and one stream synchronisation instead of nine hipMalloc/hipFree
-// and nine synchronous copies.  Never freed implicitly (a destructor at process exit would run after the HIP
-// runtime has shut down).
+// and nine synchronous copies.  A thread that ends while the process lives frees its workspace (thread_local
+// destructor below); the main thread's and whatever is left at process exit are not touched (a destructor there
+// could run after the HIP runtime has shut down; the driver reclaims everything anyway).
+static std::atomic<int> g_process_exiting{0};
 struct Workspace {
   int device = -1;
   char* d = nullptr;
@@ -130,7 +140,11 @@ struct Workspace {
       release();
       device = cur;
     }
-    if (!stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (!stream) {
+      static std::atomic<int> registered{0};  // (behind HIP's own exit handlers in the list, so it runs before them)
+      if (!registered.exchange(1)) std::atexit([] { g_process_exiting.store(1); });
+      HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    }
     if (dbytes > dcap) {
       if (d) (void)hipFree(d);
       d = nullptr, dcap = 0;
@@ -148,7 +162,15 @@ struct Workspace {
     return COLATE_OK;
   }
 };
-static thread_local Workspace g_ws;
+struct WorkspaceOwner {
+  Workspace ws;
+  ~WorkspaceOwner() {  // a short-lived worker thread must not leak HBM, pinned memory and a stream per thread
+    const bool main_thread = (::getpid() == (pid_t)::gettid());
+    if (!main_thread && !g_process_exiting.load()) ws.release();
+  }
+};
+static thread_local WorkspaceOwner g_ws_owner;
+#define g_ws (g_ws_owner.ws)
 
 // One staged call on the workspace: declare what goes in, what stays on the device and what comes out,
 // commit() (one H2D copy), launch on stream(), finish() (one D2H copy, synchronise, scatter to the caller).
@@ -221,6 +243,7 @@ class Stage {
 };
 
 static int launch(const ColateEmArgs& a, hipStream_t s) {
+  mark_device_touched();
   if (a.B == 0) return COLATE_OK;
   hipError_t e = colate_em_launch(a, s);
   if (e != hipSuccess) return hip_fail(e, "EM kernel launch");
@@ -236,7 +259,10 @@ extern "C" {
 const char* colate_version(void) { return "colate_amd 0.1 (gfx950)"; }
 const char* colate_last_error(void) { return g_last_error.c_str(); }
 
+int colate_device_touched(void) { return g_device_touched.load(std::memory_order_relaxed); }
+
 int colate_device_count(void) {
+  mark_device_touched();
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) return fail(COLATE_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
@@ -244,6 +270,7 @@ int colate_device_count(void) {
 }
 
 int colate_set_device(int ordinal) {
+  mark_device_touched();
   HIP_TRY(hipSetDevice(ordinal));
   return COLATE_OK;
 }
@@ -251,6 +278,7 @@ int colate_set_device(int ordinal) {
 int colate_warm_up(int ordinal) {
   // creates the HIP context of the device (a few hundred ms in a fresh process): a host that still has input files to
   // parse calls this from a second thread first (mut_driver.cpp)
+  mark_device_touched();
   HIP_TRY(hipSetDevice(ordinal));
   HIP_TRY(hipFree(nullptr));
   return COLATE_OK;

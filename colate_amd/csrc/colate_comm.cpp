@@ -10,8 +10,10 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "colate_amd.h"
@@ -21,6 +23,8 @@ static_assert(COLATE_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
 
 namespace {
 
+using colate::check_grids;
+using colate::ensure_device;
 using colate::fail;
 
 struct Rccl {
@@ -93,7 +97,8 @@ struct Comm {
 size_t payload_bytes(int n_max, int E) { return (size_t)n_max * ((size_t)E * 8 + 8 + 4 + 4); }
 size_t packed_bytes(int n_max, int E) { return ((payload_bytes(n_max, E) + 7) & ~size_t(7)) + 8; }
 
-int reserve(Comm* c, size_t per_rank) {
+// the two device buffers of the collective; without them this rank cannot take part in it
+int reserve_device(Comm* c, size_t per_rank) {
   if (per_rank > c->cap) {
     if (c->d_send) (void)hipFree(c->d_send);
     if (c->d_recv) (void)hipFree(c->d_recv);
@@ -102,6 +107,10 @@ int reserve(Comm* c, size_t per_rank) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_recv), per_rank * c->nranks));
     c->cap = per_rank;
   }
+  return COLATE_OK;
+}
+// the pinned landing buffer of the gathered results
+int reserve_host(Comm* c, size_t per_rank) {
   if (per_rank * c->nranks > c->hcap) {
     if (c->h_recv) (void)hipHostFree(c->h_recv);
     c->h_recv = nullptr, c->hcap = 0;
@@ -116,10 +125,16 @@ int reserve(Comm* c, size_t per_rank) {
 template <typename Local>
 int run_and_gather(Comm* c, int B, int E, double* out_rates, int* out_iters, double* out_loglik, int* out_flags,
                    Local&& local) {
+  // Everything that can fail on THIS rank before the collective is turned into `local_rc`, and the rank still joins the
+  // all-gather with its code in the trailing slot: a rank that returned early would leave the others waiting in
+  // ncclAllGather forever.  The one exception is a rank that cannot even get its two device buffers (or its device): it
+  // has nothing to join with and returns -- `Colate --ranks` (run_ranked) then ends the remaining ranks after a grace
+  // period; a host that drives the ranks itself needs the same watchdog.
   HIP_TRY(hipSetDevice(c->device));
   const int n_max = (B + c->nranks - 1) / c->nranks;
   const size_t per_rank = packed_bytes(n_max, E);
-  if (int rc = reserve(c, per_rank)) return rc;
+  if (int rc = reserve_device(c, per_rank)) return rc;
+  int local_rc = reserve_host(c, per_rank);
   int lo = 0, hi = 0;
   colate_shard_bounds(B, c->nranks, c->rank, &lo, &hi);
   auto carve = [&](char* base, double*& rates, double*& ll, int*& iters, int*& flags) {
@@ -131,15 +146,22 @@ int run_and_gather(Comm* c, int B, int E, double* out_rates, int* out_iters, dou
   double *d_rates, *d_ll;
   int *d_iters, *d_flags;
   carve(c->d_send, d_rates, d_ll, d_iters, d_flags);
-  HIP_TRY(hipMemsetAsync(c->d_send, 0, per_rank, c->stream));  // rows of a short shard beyond its n stay zero
-  int local_rc = COLATE_OK;
-  if (hi > lo) local_rc = local(hi - lo, lo, d_rates, d_ll, d_iters, d_flags, c->stream);
+  if (!local_rc) {  // rows of a short shard beyond its n stay zero
+    const hipError_t e = hipMemsetAsync(c->d_send, 0, per_rank, c->stream);
+    if (e != hipSuccess) local_rc = fail(COLATE_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+  }
+  if (const char* inj = getenv("COLATE_TEST_FAIL_RANK")) {  // failure injection for the tests of exactly this path
+    if (atoi(inj) == c->rank) local_rc = fail(COLATE_EHIP, "injected failure on rank %d (COLATE_TEST_FAIL_RANK)", c->rank);
+  }
+  if (!local_rc && hi > lo) local_rc = local(hi - lo, lo, d_rates, d_ll, d_iters, d_flags, c->stream);
+  std::string local_msg = local_rc ? colate_last_error() : "";
   if (local_rc) (void)hipMemcpyAsync(c->d_send + per_rank - 8, &local_rc, sizeof(int), hipMemcpyHostToDevice, c->stream);
   // the ONE collective of the path: per_rank bytes from every rank to every rank
   NCCL_TRY(rccl().AllGather(c->d_send, c->d_recv, per_rank, ncclChar, c->nccl, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->h_recv, c->d_recv, per_rank * c->nranks, hipMemcpyDeviceToHost, c->stream));
+  if (c->h_recv && c->hcap >= per_rank * c->nranks)
+    HIP_TRY(hipMemcpyAsync(c->h_recv, c->d_recv, per_rank * c->nranks, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (local_rc) return local_rc;  // (colate_last_error() holds this rank's own message)
+  if (local_rc) return fail(local_rc, "%s", local_msg.c_str());  // this rank's own message
   for (int r = 0; r < c->nranks; r++) {
     int code = 0;
     std::memcpy(&code, c->h_recv + (size_t)(r + 1) * per_rank - 8, sizeof(int));
@@ -191,6 +213,7 @@ int colate_shard_bounds(int B, int nranks, int rank, int* lo, int* hi) {
 
 int colate_comm_unique_id(void* id) {
   if (!id) return fail(COLATE_EINVAL, "NULL pointer argument");
+  colate::mark_device_touched();
   if (int rc = rccl_ready()) return rc;
   ncclUniqueId u;
   NCCL_TRY(rccl().GetUniqueId(&u));
@@ -201,6 +224,7 @@ int colate_comm_unique_id(void* id) {
 int colate_comm_create(const void* id, int nranks, int rank, void** comm) {
   if (!id || !comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(COLATE_EINVAL, "bad communicator arguments");
   if (int rc = rccl_ready()) return rc;
+  colate::mark_device_touched();
   Comm* c = new Comm;
   c->nranks = nranks, c->rank = rank;
   ncclUniqueId u;
@@ -239,11 +263,15 @@ int colate_em_batch_allgather(void* comm, int B, int E, int A, const double* age
                               int max_iter, int min_iter, double rel_tol, double rate_floor, double* out_rates,
                               int* out_iters, double* out_loglik, int* out_flags) {
   Comm* c = static_cast<Comm*>(comm);
-  if (!c || !age_grid || !cnt_shared || !cnt_notshared || !epochs || !init_rates || !out_rates || !out_iters ||
+  if (!age_grid || !cnt_shared || !cnt_notshared || !epochs || !init_rates || !out_rates || !out_iters ||
       !out_loglik || !out_flags)
     return fail(COLATE_EINVAL, "NULL pointer argument");
   if (B < 0 || E < 1 || A < 1 || E > COLATE_MAX_EPOCHS || A > COLATE_MAX_AGE_BINS)
     return fail(COLATE_EINVAL, "bad sizes B=%d E=%d A=%d", B, E, A);
+  // (the same inputs on every rank: a bad grid is refused by all of them alike, none enters the collective)
+  if (int rc = check_grids(E, A, age_grid, epochs)) return rc;
+  if (!c) return fail(COLATE_EINVAL, "NULL communicator");
+  if (int rc = ensure_device()) return rc;
   if (B == 0) return COLATE_OK;
   Upload up;
   return run_and_gather(c, B, E, out_rates, out_iters, out_loglik, out_flags,
@@ -266,11 +294,14 @@ int colate_bootstrap_em_batch_allgather(void* comm, int B, int nb, int E, int A,
                                         double rate_floor, double* out_rates, int* out_iters, double* out_loglik,
                                         int* out_flags) {
   Comm* c = static_cast<Comm*>(comm);
-  if (!c || !age_grid || !weights || !sh_block || !ns_block || !sh_emp_block || !ns_emp_block || !epochs ||
+  if (!age_grid || !weights || !sh_block || !ns_block || !sh_emp_block || !ns_emp_block || !epochs ||
       !init_rates || !out_rates || !out_iters || !out_loglik || !out_flags)
     return fail(COLATE_EINVAL, "NULL pointer argument");
   if (B < 0 || nb < 1 || E < 1 || A < 2 || E > COLATE_MAX_EPOCHS || A > COLATE_MAX_AGE_BINS)
     return fail(COLATE_EINVAL, "bad sizes B=%d nb=%d E=%d A=%d", B, nb, E, A);
+  if (int rc = check_grids(E, A, age_grid, epochs)) return rc;
+  if (!c) return fail(COLATE_EINVAL, "NULL communicator");
+  if (int rc = ensure_device()) return rc;
   if (B == 0) return COLATE_OK;
   Upload up;
   int* d_status = nullptr;

@@ -2,9 +2,10 @@
 //
 //   shape                                   instantiation                     build
 //   one E-step (colate_em_estep)            <1, NCH, 4, false>                this unit
-//   B <= #CUs, E <= 128                     <0, NCH, EROWS, false> latency    em_kernels_ilp.hip (max-ilp scheduling)
-//   #CUs < B <= 2 x #CUs, E <= 128          <0, NCH, EROWS, false> latency    this unit (3 waves/SIMD: two workgroups per CU)
+//   B <= 2 x #CUs, E <= 128                 <0, NCH, EROWS, false> latency    em_kernels_ilp.hip (max-ilp scheduling; fits 3 waves/SIMD)
+//   only by COLATE_EM_VARIANT=latency       <0, NCH, EROWS, false> latency    this unit (default scheduler; A/B runs)
 //   B > 2 x #CUs, or E > 128                <0, NCH, EROWS, true> throughput  this unit
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -14,28 +15,37 @@ hipError_t colate_em_launch_latency_ilp(const ColateEmArgs& args, hipStream_t st
 
 size_t colate_em_lds_bytes(int E, int A) { return em_lds_bytes(E, A); }
 
-// number of CUs of the current device (cached per ordinal)
+// number of CUs of the current device (cached per ordinal; atomics: launches may come from several host threads)
 static int device_cus() {
-  static int cus[64] = {0};
+  static std::atomic<int> cus[64];  // 0 = not asked yet, -1 = the query failed
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-  if (cus[dev] == 0) {
-    int n = 0;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = -1;
-    cus[dev] = n;
+    cus[dev].store(n, std::memory_order_relaxed);  // (two threads asking at once store the same value)
   }
-  return cus[dev] > 0 ? cus[dev] : 0;
+  return n > 0 ? n : 0;
 }
 
-// 0 = latency (max-ilp build), 1 = latency (default build), 2 = throughput.
-// COLATE_EM_VARIANT=latency|latency-ilp|throughput overrides the choice for E <= 128 (tests, experiments).
-int colate_em_variant(int B, int E) {
-  if (em_chunks(E) > 2) return 2;  // 129..256 epochs: only the two-wave layout fits the register file without scratch
-  if (const char* v = getenv("COLATE_EM_VARIANT")) {
+// COLATE_EM_VARIANT=latency|latency-ilp|throughput overrides the choice of build for E <= 128 (tests, A/B runs).
+// Read once per process, not per launch.
+static int variant_override() {
+  static const int forced = [] {
+    const char* v = getenv("COLATE_EM_VARIANT");
+    if (!v) return -1;
     if (!strcmp(v, "throughput")) return 2;
     if (!strcmp(v, "latency")) return 1;
     if (!strcmp(v, "latency-ilp")) return 0;
-  }
+    return -1;
+  }();
+  return forced;
+}
+
+// 0 = latency (max-ilp build), 1 = latency (default build), 2 = throughput.
+int colate_em_variant(int B, int E) {
+  if (em_chunks(E) > 2) return 2;  // 129..256 epochs: only the two-wave layout fits the register file without scratch
+  if (variant_override() >= 0) return variant_override();
   // Measured (tools/variant_sweep.sh, profiles/r02/variants.txt): since the steady-state loops the max-ilp build fits
   // 3 waves per SIMD as well (157 VGPRs) and is the faster latency build at every batch size (1.29 against 1.33 ms at
   // B = 400); two 6-wave workgroups per CU beat the two-wave layout up to 2 x #CUs (B = 512: 1.30 against 2.09 ms),

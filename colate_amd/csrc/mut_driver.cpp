@@ -13,7 +13,10 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <signal.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -526,7 +529,15 @@ int run_mut(const Options& opt) {
       if (t.joinable()) t.join();
     }
   } warm;
-  if (!g_rank.ranked && !opt.has("devices") && !opt.has("counts_only")) warm.t = std::thread([] { (void)colate_warm_up(0); });
+  if (!g_rank.ranked && !opt.has("devices") && !opt.has("counts_only")) {
+    int warm_dev = 0;  // the device the run will use (--device N)
+    try {
+      if (opt.has("device")) warm_dev = std::stoi(opt.get("device"));
+    } catch (...) {
+      warm_dev = 0;  // (reported where the option is used)
+    }
+    warm.t = std::thread([warm_dev] { (void)colate_warm_up(warm_dev); });
+  }
 
   double target_age = 0, ref_age = 0;
   try {
@@ -696,6 +707,10 @@ int run_mut(const Options& opt) {
   int rc;
   if (g_rank.ranked) {
     // one process per GPU: this rank's contiguous replicate range on its own device, then ONE RCCL all-gather
+    if (const char* h = std::getenv("COLATE_TEST_HANG_RANK")) {  // test hook: a rank stuck as if inside a collective
+      if (std::atoi(h) == g_rank.rank)
+        for (;;) ::pause();
+    }
     const int ndev = colate_device_count();
     if (ndev < 1) {
       std::cerr << "Error: " << colate_last_error() << std::endl;
@@ -1136,6 +1151,14 @@ int run_make_tmp(const Options& opt) {
 // contiguous range of replicates and takes part in one RCCL all-gather (colate_comm.cpp); rank 0 writes the outputs.
 // The launcher only relays rank 0's 128-byte communicator id to the other ranks and collects the exit codes.
 int run_ranked(const Options& opt, int nranks) {
+  if (colate_device_touched()) {
+    // fork() after the HIP runtime is up gives children with a half-copied runtime (its threads and device queues are
+    // not duplicated): they hang or fault.  The command-line `Colate` never gets here; a host process that has already
+    // computed through this library (or that shares it with torch) must start the ranks as fresh processes instead.
+    std::cerr << "Error: --ranks forks one process per GPU and must run before this process first uses a GPU through "
+                 "libcolate_amd; start `Colate --ranks N` as its own process (never re-exec from here)." << std::endl;
+    return 1;
+  }
   if (!opt.has("seed")) {
     std::cerr << "Error: --ranks needs --seed (every rank must draw the same bootstrap weights)." << std::endl;
     return 1;
@@ -1203,15 +1226,43 @@ int run_ranked(const Options& opt, int nranks) {
     for (int r = 1; r < nranks; r++) write_all(down_w[r], id, sizeof(id));
   ::close(up[0]);
   for (int r = 1; r < nranks; r++) ::close(down_w[r]);
-  int worst = 0;
-  for (int r = 0; r < nranks; r++) {
-    int st = 0;
-    if (::waitpid(pids[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
-      std::cerr << "Error: rank " << r << " failed";
-      if (r > 0) std::cerr << " (see " << opt.get("output") << ".rank" << r << ".stderr)";
-      std::cerr << std::endl;
-      worst = 1;
+  // Reap the ranks as they end (our own pids only: this function is also reachable through the library ABI, whose host
+  // may have children of its own).  A rank that fails before or outside the collective leaves the others waiting in
+  // ncclCommInitRank / ncclAllGather for ever, so the first failure starts a grace period (COLATE_RANK_GRACE_SEC, default
+  // 15 s: ranks that are merely finishing get there) after which the remaining ranks are killed.
+  double grace_s = 15.0;
+  if (const char* g = std::getenv("COLATE_RANK_GRACE_SEC")) grace_s = std::atof(g);
+  int worst = 0, remaining = nranks;
+  std::vector<char> done(nranks, 0);
+  bool failing = false, killed = false;
+  auto t_fail = std::chrono::steady_clock::now();
+  while (remaining > 0) {
+    bool progressed = false;
+    for (int r = 0; r < nranks; r++) {
+      if (done[r]) continue;
+      int st = 0;
+      const pid_t w = ::waitpid(pids[r], &st, WNOHANG);
+      if (w == 0) continue;
+      done[r] = 1, remaining--, progressed = true;
+      const bool ok = (w == pids[r]) && WIFEXITED(st) && WEXITSTATUS(st) == 0;
+      if (!ok) {
+        std::cerr << "Error: rank " << r << (killed ? " was ended by the launcher" : " failed");
+        if (r > 0) std::cerr << " (see " << opt.get("output") << ".rank" << r << ".stderr)";
+        std::cerr << std::endl;
+        worst = 1;
+        if (!failing) failing = true, t_fail = std::chrono::steady_clock::now();
+      }
     }
+    if (remaining == 0) break;
+    if (failing && !killed &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fail).count() > grace_s) {
+      std::cerr << "Error: a rank failed; ending the " << remaining << " rank(s) still waiting after " << grace_s << " s."
+                << std::endl;
+      for (int r = 0; r < nranks; r++)
+        if (!done[r]) ::kill(pids[r], SIGKILL);
+      killed = true;
+    }
+    if (!progressed) ::usleep(20000);
   }
   return worst;
 }

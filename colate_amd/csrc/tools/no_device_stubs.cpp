@@ -28,6 +28,7 @@ static int nodev() { return colate::fail(COLATE_ENODEVICE, "host sanitizer build
 extern "C" {
 const char* colate_version(void) { return "colate_amd host sanitizer build (no device code)"; }
 const char* colate_last_error(void) { return colate::g_err.c_str(); }
+int colate_device_touched(void) { return 0; }
 int colate_device_count(void) { return nodev(); }
 int colate_set_device(int) { return nodev(); }
 int colate_warm_up(int) { return nodev(); }

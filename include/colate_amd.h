@@ -52,7 +52,9 @@ extern "C" {
  * fixed point: it is made for runs that end by the stop rule at the reference's tolerance (COLATE_DEFAULT_REL_TOL); a run cut
  * by max_iter (COLATE_FLAG_MAXITER) or stopped at a looser tolerance still carries its path. */
 #define COLATE_FLAG_UNRESOLVED 8
-#define COLATE_STATUS_FLAGS(flags) ((flags) & 0xff)
+/* the error-like bits (NAN | NEG | MAXITER): COLATE_STATUS_FLAGS(f) != 0 means "the reference would have aborted, or the
+ * iteration cap ended the run"; COLATE_FLAG_UNRESOLVED is deliberately not part of it */
+#define COLATE_STATUS_FLAGS(flags) ((flags) & 0x07)
 #define COLATE_UNRESOLVED_EPOCHS(flags) ((int)((unsigned)(flags) >> 8))
 
 /* compiled limits of the EM kernel: one epoch / one age bin per thread of a 256-thread workgroup */
@@ -73,6 +75,10 @@ int colate_set_device(int ordinal);  /* device used by the calling thread's late
 /* Creates the device's HIP context now (from any thread) instead of inside the first compute call: lets a host overlap
  * the few hundred ms a fresh process pays for it with its own input parsing.  No reference counterpart (CPU code). */
 int colate_warm_up(int ordinal);
+/* 1 once this process has talked to the HIP runtime through this library (any compute or device entry point), else 0.
+ * Such a process must not fork() children that use the GPU: colate_mut_main refuses `--ranks N` (which forks one
+ * process per GPU) when this is set -- start `Colate --ranks N` as a fresh process instead. */
+int colate_device_touched(void);
 /* Diagnostic: which build of the EM kernel a batch of this shape runs on the current device
  * (0 latency/max-ilp, 1 latency/default scheduler, 2 throughput), or a negative code. */
 int colate_em_kernel_variant(int B, int E);

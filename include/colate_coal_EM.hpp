@@ -47,6 +47,8 @@ class coal_EM {
     const int rc = colate_em_estep(1, E, 1, &age_begin, shared ? &one_count : &zero, shared ? &zero : &one_count,
                                    epochs_.data(), coal_rates_.data(), num.data(), denom.data(), &loglik, &flags);
     if (rc != COLATE_OK) throw std::runtime_error(std::string("colate_em_estep: ") + colate_last_error());
+    if (flags & (COLATE_FLAG_NAN | COLATE_FLAG_NEG))  // the reference aborts here (coal.cpp:3711-3714, coal_EM.cpp:128-129, 351)
+      throw std::runtime_error("colate::coal_EM: NaN or negative sufficient statistics (the reference asserts on these)");
     return loglik;
   }
   std::vector<double> epochs_, coal_rates_;

@@ -327,3 +327,78 @@ def test_colate_mat_writer_is_read_by_the_reference(tmp_path):
     rates, iters, _, _ = ol.em_batch(grid, csh, cns, ep)
     assert iters.tolist() == case["iterations"]
     assert gl.coal_text(ep, rates) == open(os.path.join(src, "expected.coal")).read()
+
+
+def test_allgather_entry_points_check_their_grids():
+    """colate_em_batch_allgather / colate_bootstrap_em_batch_allgather refuse unsorted grids like every other
+    host-pointer entry point (before any rank could enter the collective) -- checked without a communicator."""
+    from colate_amd._lib import lib
+
+    A, E, B, nb = 185, 23, 2, 3
+    grid = np.ascontiguousarray(ol.age_grid())
+    ep, _ = ol.epochs_from_bins("3,7,0.2", 0.0, 28.0)
+    bad = np.ascontiguousarray(ep[::-1])
+    cnt = np.ones((B, A))
+    init = np.full(E, 5e-5)
+    rates, ll = np.zeros((B, E)), np.zeros(B)
+    iters, flags = np.zeros(B, np.int32), np.zeros(B, np.int32)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+
+    def em(epochs):
+        return lib.colate_em_batch_allgather(None, B, E, A, ptr(grid), ptr(cnt), ptr(cnt), ptr(epochs), ptr(init), 10, 0,
+                                             1e-7, 5e-9, ptr(rates), ptr(iters), ptr(ll), ptr(flags))
+
+    assert em(bad) == -1 and b"non-decreasing" in lib.colate_last_error()
+    assert em(np.ascontiguousarray(ep)) == -1 and b"communicator" in lib.colate_last_error()
+    tabs = np.ones((nb, A))
+    w = np.ones((B, nb))
+    rc = lib.colate_bootstrap_em_batch_allgather(None, B, nb, E, A, ptr(grid), 0.0, ptr(w), ptr(tabs), ptr(tabs), ptr(tabs),
+                                                 ptr(tabs), ptr(bad), ptr(init), 10, 0, 1e-7, 5e-9, ptr(rates), ptr(iters),
+                                                 ptr(ll), ptr(flags))
+    assert rc == -1 and b"non-decreasing" in lib.colate_last_error()
+
+
+def test_status_flags_macro_matches_python(ca):
+    header = open(os.path.join(ROOT, "include", "colate_amd.h")).read()
+    m = re.search(r"#define COLATE_STATUS_FLAGS\(flags\) \(\(flags\) & (0x[0-9a-f]+)\)", header)
+    assert m and int(m.group(1), 16) == ca.STATUS_MASK == 0x07  # UNRESOLVED (8) is not an error bit
+
+
+def test_ranks_launcher_ends_waiting_ranks_after_a_failure(tmp_path):
+    """`Colate --ranks 2` where rank 1 hangs (as a rank blocked in a collective whose peer died would) and rank 0
+    fails: the launcher must kill the survivor after the grace period and exit non-zero instead of waiting forever."""
+    import time
+
+    mat = tmp_path / "out.colate_mat"  # the .colate_mat hook: no readers needed to reach the ranked section
+    grid = ol.age_grid()
+    with open(mat, "w") as f:
+        f.write(" ".join(repr(float(x)) for x in grid) + "\n")
+        for _ in range(2):
+            f.write(" ".join("1" for _ in grid) + "\n")
+            f.write(" ".join("2" for _ in grid) + "\n")
+    env = dict(os.environ, COLATE_TEST_HANG_RANK="1", COLATE_RANK_GRACE_SEC="1", HIP_VISIBLE_DEVICES="",
+               ROCR_VISIBLE_DEVICES="")
+    t0 = time.time()
+    r = subprocess.run([CLI, "--mode", "mut", "--mut", "dummy", "--bins", "3,7,0.2", "--num_bootstraps", "2", "--seed", "1",
+                        "--ranks", "2", "-o", str(tmp_path / "out")], env=env, capture_output=True, text=True, timeout=60)
+    took = time.time() - t0
+    assert r.returncode != 0
+    assert "rank 0 failed" in r.stderr and "ended by the launcher" in r.stderr, r.stderr
+    assert took < 30
+
+
+def test_ranks_refused_once_the_process_has_used_the_device(ca, tmp_path):
+    """colate_mut_main --ranks forks one process per GPU: refused (never forked, never re-exec'd) in a process whose HIP
+    runtime is already up."""
+    code = (
+        "import sys, ctypes\n"
+        "from colate_amd._lib import lib\n"
+        "assert lib.colate_device_touched() == 0\n"
+        "lib.colate_device_count()\n"
+        "assert lib.colate_device_touched() == 1\n"
+        "argv = [b'Colate', b'--mode', b'mut', b'--mut', b'x', b'--bins', b'3,7,0.2', b'--seed', b'1', b'--ranks', b'2', b'-o', sys.argv[1].encode()]\n"
+        "arr = (ctypes.c_char_p * len(argv))(*argv)\n"
+        "sys.exit(lib.colate_mut_main(len(argv), arr))\n"
+    )
+    r = subprocess.run([os.sys.executable, "-c", code, str(tmp_path / "o")], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "must run before this process first uses a GPU" in r.stderr, (r.returncode, r.stderr)
