@@ -37,6 +37,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_CLOCK_HZ = 2.4e9  # same guide: max clock
+# FP64 vector peak: half the guide's FP32 vector peak (157.3 TFLOP/s = 256 CUs x 4 SIMD-32 x 2 flop x 2.4 GHz); an FP64
+# wave instruction occupies its SIMD for 4 cycles (csrc/tools/ubench.hip: ~5 per independent v_fma_f64 on a lone wave)
+FP64_VALU_PEAK_TFLOPS = 78.6
+TIMED_REGION_S = 0.6  # the timed region lasts at least this long whatever --steps is (see `passes_per_step`)
 BINS = "3,7,0.2"
 B_PER_GPU = 100
 CPU_SAMPLE = 64  # replicates timed on the host (about 10 s on one core at 23 epochs)
@@ -51,6 +55,8 @@ def parse_args():
     ap.add_argument("--total-replicates", type=int, default=0,
                     help="strong scaling: this many replicates in total, sharded over the GPUs (BASELINE configs[2]: 1000)")
     ap.add_argument("--bins", default=BINS, help="epoch grid (default: the BASELINE config; 2,7.95,0.05 = 122 epochs)")
+    ap.add_argument("--passes-per-step", type=int, default=0,
+                    help="passes of the hot path per step (0 = chosen so that the timed region lasts >= %.1f s)" % TIMED_REGION_S)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive (host-pointer ABI) timing")
     ap.add_argument("--no-cxx-rccl-check", action="store_true",
@@ -165,6 +171,52 @@ def cpu_baseline(grid, csh, cns, epochs, gpu_rates, gpu_iters, bins=BINS):
         "sample": f"{S} of the benchmark's replicates through oracle/liboracle.so, {dt:.1f} s",
         "max_rel_diff_vs_gpu": float(rel.max()), "iters_equal": bool((iters == gpu_iters[:S]).all()),
     }
+
+
+def roofline(pmc, hbm_algorithmic_gbs, kern_ms, kernel_name, variant, algorithmic_bytes, n_local, cus, rounds, crit_iters):
+    """The bench line's `roofline` object.  SURVEY.md section 8(d)'s HBM line (algorithmic bytes / kernel time against the
+    8 TB/s peak) is kept under `hbm`; the TOP-LEVEL bound is what limits the kernel: FP64 vector issue.  The kernel keeps
+    its working set on chip (counter traffic is ~0.002 x the algorithmic bytes), so HBM is a label here, not a bound."""
+    hbm = {
+        "bound": "hbm", "achieved": hbm_algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": hbm_algorithmic_gbs / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_launch": algorithmic_bytes,
+        "achieved_from_counters": (pmc["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9) if pmc else None,
+        "note": "achieved = algorithmic bytes ((2*A*8 + A*8 + 3*E*8) B per replicate-iteration x E-steps per launch, SURVEY.md "
+                "section 8d) / kernel time; achieved_from_counters = FETCH_SIZE/WRITE_SIZE bytes per launch (profiles/pmc.json) / "
+                "kernel time: what the kernel really asks of HBM",
+    }
+    latency = {
+        "what": "one workgroup per replicate runs its EM iterations back to back; an iteration is a chain of dependent FP64 "
+                "instructions through the two role leaders and three LDS hand-overs, so a CU's vector units are busy only "
+                "while one of its (few) waves has an instruction in flight",
+        "workgroups": n_local, "cus": cus, "cus_occupied": min(n_local, cus), "workgroup_rounds": rounds,
+        "em_iterations_on_critical_path": crit_iters * rounds,
+        "ns_per_em_iteration": 1e6 * kern_ms / (crit_iters * rounds),
+        "cycles_per_em_iteration_at_peak_clock": kern_ms * 1e-3 * PEAK_CLOCK_HZ / (crit_iters * rounds),
+        "pmc": ({k: pmc[k] for k in pmc if k not in ("workload", "hbm_bytes_per_launch")} if pmc else None),
+    }
+    common = {"traffic": pmc["hbm_bytes_per_launch"] if pmc else None, "kernel": kernel_name, "kernel_build": variant,
+              "kernel_ms": kern_ms, "hbm": hbm, "latency": latency}
+    if not pmc or "sq_active_inst_valu" not in pmc:
+        # no counter record for this shape under profiles/: only the HBM line can be given
+        return dict(hbm, **common, note="no PMC record for this workload in profiles/pmc.json: the FP64-VALU bound is not "
+                                        "priced; see `latency`")
+    # VALUBusy as rocprof defines it: quad-cycles with a VALU instruction executing, summed over waves, against the
+    # SIMD-cycles of the whole chip during THIS run's kernel time
+    busy_chip = 4.0 * pmc["sq_active_inst_valu"] / (kern_ms * 1e-3 * PEAK_CLOCK_HZ * 4 * cus)
+    occupied = min(n_local, cus) / cus if rounds == 1 else 1.0
+    return dict({
+        "bound": "fp64-valu",
+        "achieved": busy_chip * FP64_VALU_PEAK_TFLOPS, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": busy_chip,
+        "valu_busy_frac_of_occupied_cus": busy_chip / occupied,
+        "note": "frac = share of the chip's vector-issue cycles (256 CUs x 4 SIMDs x kernel time at the 2.4 GHz peak clock) in "
+                "which a VALU instruction was executing (SQ_ACTIVE_INST_VALU of the committed PMC pass, profiles/pmc.json, over "
+                "the kernel time measured live); achieved = frac x the FP64 vector peak, i.e. issue-equivalent TFLOP/s, not counted "
+                "flops.  At B <= #CUs only B CUs are occupied by 4 live waves each (valu_busy_frac_of_occupied_cus) and the time "
+                "is the latency of one EM iteration (`latency`); the HBM line SURVEY.md section 8(d) asks for is under `hbm`.",
+    }, **common)
 
 
 def emit(out):
@@ -292,7 +344,7 @@ def run_rank(args):
         if stream is not None:
             stream.synchronize()
 
-    def step(events=None):
+    def one_pass(events=None):
         """counts resident in HBM -> every rank holds all B_total results in host memory"""
         if events:
             events[0].record(stream)  # on the stream the kernel is launched on
@@ -308,6 +360,8 @@ def run_rank(args):
             h_local.copy_(d_out, non_blocking=True)
             sync()
             cd.all_gather_shards(h_local, layout, dist, out=h_all)
+        if events:
+            events[2].record(stream)
         sync()
 
     def fence():
@@ -318,20 +372,47 @@ def run_rank(args):
         if not dry:
             torch.cuda.synchronize()
 
+    # A step = `passes` passes of the hot path over the batch, each complete (launch -> gather -> host copy -> sync).
+    # One pass takes about a millisecond, so 20 one-pass steps would be a 20 ms timed region -- too short for anything
+    # outside this process (the driver's GPU-busy sampling) to see; `passes` is chosen from the warm-up so that
+    # steps x passes lasts >= TIMED_REGION_S, the same on every rank, and stated in config.passes_per_step.
     for _ in range(args.warmup):
-        step()
+        one_pass()
     fence()
-    ev = None if dry else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    passes = args.passes_per_step
+    if passes <= 0:
+        t_w = time.perf_counter()
+        for _ in range(3):
+            one_pass()
+        est = max((time.perf_counter() - t_w) / 3, 1e-5)
+        passes = 1 if dry else max(1, int(np.ceil(TIMED_REGION_S / (args.steps * est))))
+        if world > 1:
+            t = torch.tensor([passes], dtype=torch.int64, device=cd.collective_device(dist))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            passes = int(t.item())
+    n_pass = args.steps * passes
+    fence()
+    mk = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    n_ev = min(n_pass, 256)  # HIP events around the kernel (and around gather + copy) of the first passes
+    ev = None if dry else [(mk(), mk(), mk()) for _ in range(n_ev)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(ev[k] if ev else None)
+    for k in range(n_pass):
+        one_pass(ev[k] if (ev and k < n_ev) else None)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cd.collective_device(dist))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if (n_local and ev) else float("nan")
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev])) if (n_local and ev) else float("nan")
+    gather_ms = float(np.mean([b.elapsed_time(c) for _, b, c in ev])) if ev else float("nan")
+    # per-rank kernel and gather(+copy) times, so that an inefficiency at N > 1 can be attributed (rank 0 reports them)
+    per_rank = [[kern_ms, gather_ms]]
+    if world > 1:
+        mine = torch.tensor([kern_ms, gather_ms], dtype=torch.float64, device=cd.collective_device(dist))
+        allr = torch.empty(world * 2, dtype=torch.float64, device=mine.device)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank = allr.cpu().view(world, 2).tolist()
     rates_all, iters_all, ll_all, flags_all = layout.unpack(h_all)  # every rank has every replicate's results
 
     # launches enqueued back to back without the per-step copy and synchronisation (N = 1 only; not `value`)
@@ -339,11 +420,11 @@ def run_rank(args):
     if world == 1 and not dry:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(n_pass):
             launch()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
-        device_only = {"value": B_total * args.steps / dt, "unit": "replicates/s", "ms_per_step": 1e3 * dt / args.steps,
+        device_only = {"value": B_total * n_pass / dt, "unit": "replicates/s", "ms_per_pass": 1e3 * dt / n_pass,
                        "note": "launches enqueued back to back, no per-step copy of the rates to the host and no "
                                "per-step synchronisation (round 1's definition of `value`)"}
 
@@ -374,7 +455,7 @@ def run_rank(args):
         waves = -(-n_local // cus)
         out = {
             "metric": "bootstrap replicates/sec to EM convergence, whole-genome SGDP mut, 20 epochs",
-            "value": None if dry else B_total * args.steps / elapsed,
+            "value": None if dry else B_total * n_pass / elapsed,
             "unit": "replicates/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -393,35 +474,16 @@ def run_rank(args):
                 "parallelism": f"replicates sharded over {world} GPU(s), one "
                                + ("RCCL" if (world > 1 and on_gpu) else ("gloo (rehearsal)" if world > 1 else "(no)"))
                                + " all-gather of rates/loglik/iterations/flags per step",
-                "step": "EM kernel launch -> all-gather (N > 1) -> results copied to host memory -> stream synchronised, all timed",
+                "step": f"{passes} passes, each: EM kernel launch -> all-gather (N > 1) -> results copied to host memory -> "
+                        "stream synchronised, all timed",
+                "passes_per_step": passes, "ms_per_pass": 1e3 * elapsed / n_pass, "timed_region_s": elapsed,
+                "per_rank_ms": {"kernel": [x[0] for x in per_rank], "gather_and_copy": [x[1] for x in per_rank],
+                                "note": "HIP events on the launch stream, mean over the timed passes, one entry per rank"},
                 "em_iterations_mean": float(iters_all.mean()), "status_flags_nonzero": int((status != 0).sum()),
                 "unresolved_epochs_max": int(unresolved.max()),
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
-                "kernel": kernel_name,
-                "kernel_build": variant,
-                "kernel_ms": kern_ms,
-                "algorithmic_bytes_per_launch": esteps * bytes_per_rep_iter,
-                "note": "algorithmic bytes = (2*A*8 + A*8 + 3*E*8) B per replicate-iteration x E-steps per launch "
-                        "(SURVEY.md section 8d); the kernel keeps all of it on chip (compulsory HBM traffic is "
-                        "(2*A + E)*8 B per replicate, see `traffic`), so this fraction only says that nothing is re-read; "
-                        "what bounds the kernel is in `latency`",
-                "latency": {
-                    "what": "the kernel is bound by the latency of one EM iteration's chain of dependent FP64 instructions "
-                            "(one workgroup per replicate; iterations are sequential by construction of EM)",
-                    "workgroups": n_local, "cus": cus, "cus_occupied": min(n_local, cus), "workgroup_rounds": waves,
-                    "em_iterations_on_critical_path": crit_iters * waves,
-                    "ns_per_em_iteration": 1e6 * kern_ms / (crit_iters * waves),
-                    "cycles_per_em_iteration_at_peak_clock": kern_ms * 1e-3 * PEAK_CLOCK_HZ / (crit_iters * waves),
-                    "pmc": ({k: pmc[k] for k in pmc if k not in ("workload", "hbm_bytes_per_launch")} if pmc else None),
-                },
-            },
+            "roofline": roofline(pmc, achieved, kern_ms, kernel_name, variant, esteps * bytes_per_rep_iter, n_local, cus,
+                                 waves, crit_iters),
         }
         if device_only:
             out["device_only"] = device_only

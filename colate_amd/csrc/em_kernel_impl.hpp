@@ -934,6 +934,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     }
     COLATE_STAMP(4)
     __syncthreads();  // ---- barrier 3: partial N, D visible
+    COLATE_STAMP(6)
     // ============================================================ P4: M-step (every wave) and stop rule
     double N_e[NCH], D_e[NCH];
 #pragma unroll
@@ -946,6 +947,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         if (N_e[c] < 0.0 || D_e[c] < 0.0) my_flags |= COLATE_FLAG_NEG;          // coal.cpp:3713-3714
       }
     }
+    COLATE_STAMP(13)
     if (need_ll) {
       COLATE_COLD();
       ll = ((s_ll[0] + s_ll[1]) + (s_ll[2] + s_ll[3])) + ((s_ll[4] + s_ll[5]) + (s_ll[6] + s_ll[7]));  // retired waves: 0

@@ -67,8 +67,8 @@ int main(int argc, char** argv) {
 #ifndef COLATE_EM_STAMPS
   return 0;
 #endif
-  const char* names[16] = {"P2 start (gathers)", "P2 bin math", "P2 seg-reduce+store", "barrier 2", "P3 N,D + store", "P4 M-step", "-", "loop top/stop",
-                           "P1 cs scan", "P1 exp/div/write", "P3 tail loads", "P3 suffix scan (A)", "P3 affine scan (B)", "-", "-", "-"};
+  const char* names[16] = {"P2 start (gathers)", "P2 bin math", "P2 seg-reduce+store", "barrier 2", "P3 N,D + store", "P4 divide+masks", "P4 wait at barrier 3", "loop top/stop",
+                           "P1 cs scan", "P1 exp/div/write", "P3 tail loads", "P3 suffix scan (A)", "P3 affine scan (B)", "P4 N,D LDS loads+adds", "-", "-"};
   for (int w = 0; w < 2; w++) {
     unsigned long long tot = 0;
     for (int i = 0; i < 16; i++) tot += dbg[(size_t)w * 16 + i];

@@ -63,6 +63,12 @@ def pmc_entry(src, fetch_factor, note):
         "wait_any_frac_of_wave_cycles": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
         "wait_inst_any_frac_of_wave_cycles": m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"],
         "waves_per_launch": waves,
+        # what really bounds the kernel (bench.py's top-level `roofline`): the share of the chip's vector-issue cycles in
+        # which a VALU instruction was executing.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; the kernel
+        # lasted GRBM_GUI_ACTIVE / 8 clocks (the counter is summed over the 8 XCDs); 256 CUs x 4 SIMDs can be busy.
+        "sq_active_inst_valu": m["SQ_ACTIVE_INST_VALU"], "sq_wave_cycles": m["SQ_WAVE_CYCLES"],
+        "grbm_gui_active": m["GRBM_GUI_ACTIVE"],
+        "valu_busy_frac_chip": 4.0 * m["SQ_ACTIVE_INST_VALU"] / (m["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
         "valu_insts_per_wave_per_em_iteration": m["SQ_INSTS_VALU"] / waves / iters,
         "salu_insts_per_wave_per_em_iteration": m["SQ_INSTS_SALU"] / waves / iters,
         "lds_insts_per_wave_per_em_iteration": m["SQ_INSTS_LDS"] / waves / iters,
