@@ -15,6 +15,7 @@ from .api import (  # noqa: F401
     FLAG_NEG,
     FLAG_UNRESOLVED,
     STATUS_MASK,
+    em_force_variant,
     em_kernel_variant,
     status_flags,
     unresolved_epochs,

@@ -35,6 +35,7 @@ SIGNATURES = {
     "colate_warm_up": (c_int, [c_int]),
     "colate_device_touched": (c_int, []),
     "colate_em_kernel_variant": (c_int, [c_int, c_int]),
+    "colate_em_force_variant": (c_int, [c_int]),
     "colate_em_batch": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "colate_em_batch_device": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -51,6 +51,11 @@ def em_kernel_variant(B, E):
     return EM_VARIANTS[check(lib.colate_em_kernel_variant(int(B), int(E)))]
 
 
+def em_force_variant(name=None):
+    """Force the build of the EM kernel for E <= 128 ("latency-ilp", "latency", "throughput"); None = automatic."""
+    check(lib.colate_em_force_variant(-1 if name is None else EM_VARIANTS.index(name)))
+
+
 def age_grid():
     """coal.cpp:3126-3137."""
     g = np.zeros(256)

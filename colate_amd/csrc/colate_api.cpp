@@ -290,6 +290,11 @@ int colate_em_kernel_variant(int B, int E) {
   return colate_em_variant(B, E);
 }
 
+int colate_em_force_variant(int variant) {
+  colate_em_set_forced_variant(variant);
+  return COLATE_OK;
+}
+
 int colate_em_batch_device(int B, int E, int A, const double* age_grid, const double* cnt_shared,
                            const double* cnt_notshared, const double* epochs,
                            int epochs_per_replicate, const double* init_rates,

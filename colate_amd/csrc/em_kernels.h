@@ -40,6 +40,8 @@ hipError_t colate_em_launch(const ColateEmArgs& args, hipStream_t stream);
 // which build of the kernel a launch of this shape picks on the current device:
 // 0 = latency (max-ilp build), 1 = latency (default build), 2 = throughput (em_kernels.hip)
 int colate_em_variant(int B, int E);
+// force the build for E <= 128 (0, 1, 2 as above; anything else = automatic again)
+void colate_em_set_forced_variant(int v);
 
 // block bootstrap on the device (bootstrap_kernel.hip)
 hipError_t colate_bootstrap_launch(int B, int nb, int A, const double* age_grid, double age,

@@ -28,19 +28,22 @@ static int device_cus() {
   return n > 0 ? n : 0;
 }
 
-// COLATE_EM_VARIANT=latency|latency-ilp|throughput overrides the choice of build for E <= 128 (tests, A/B runs).
-// Read once per process, not per launch.
-static int variant_override() {
-  static const int forced = [] {
+// Which build a launch takes for E <= 128 can be forced (tests, A/B runs): at run time by colate_em_force_variant()
+// (include/colate_amd.h), initially by COLATE_EM_VARIANT=latency|latency-ilp|throughput, which is read ONCE per process
+// (not per launch).  -1 = automatic.
+static std::atomic<int>& variant_forced() {
+  static std::atomic<int> forced{[] {
     const char* v = getenv("COLATE_EM_VARIANT");
     if (!v) return -1;
     if (!strcmp(v, "throughput")) return 2;
     if (!strcmp(v, "latency")) return 1;
     if (!strcmp(v, "latency-ilp")) return 0;
     return -1;
-  }();
+  }()};
   return forced;
 }
+void colate_em_set_forced_variant(int v) { variant_forced().store((v >= 0 && v <= 2) ? v : -1, std::memory_order_relaxed); }
+static int variant_override() { return variant_forced().load(std::memory_order_relaxed); }
 
 // 0 = latency (max-ilp build), 1 = latency (default build), 2 = throughput.
 int colate_em_variant(int B, int E) {

@@ -32,6 +32,7 @@ int colate_device_touched(void) { return 0; }
 int colate_device_count(void) { return nodev(); }
 int colate_set_device(int) { return nodev(); }
 int colate_warm_up(int) { return nodev(); }
+int colate_em_force_variant(int) { return nodev(); }
 int colate_em_batch(int, int, int, const double*, const double*, const double*, const double*, const double*, int, int,
                     double, double, double*, int*, double*, int*) { return nodev(); }
 int colate_em_batch_rows(int, int, int, const double*, const double*, const double*, const double*, const double*, int, int,

@@ -82,6 +82,9 @@ int colate_device_touched(void);
 /* Diagnostic: which build of the EM kernel a batch of this shape runs on the current device
  * (0 latency/max-ilp, 1 latency/default scheduler, 2 throughput), or a negative code. */
 int colate_em_kernel_variant(int B, int E);
+/* Diagnostic: force that choice for E <= 128 (0, 1 or 2; any other value = automatic again).  Process-wide.  The
+ * environment variable COLATE_EM_VARIANT=latency-ilp|latency|throughput sets the initial value (read once). */
+int colate_em_force_variant(int variant);
 
 /* ---- the EM hot path ------------------------------------------------------
  * Replaces coal.cpp:3675-3827 (bootstrap EM driver: coal_EM construction,

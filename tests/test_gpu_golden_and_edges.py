@@ -317,7 +317,7 @@ def test_sharded_entry_point_matches_single_launch(ca):
         ca.em_batch_sharded([99], grid, csh, cns, ep)
 
 
-def test_throughput_variant_is_bit_identical(ca, monkeypatch):
+def test_throughput_variant_is_bit_identical(ca):
     """The kernel has a latency variant (a wave per role and bin group; B up to twice the CU count; built twice:
     max-ilp scheduling -- the one the library picks -- and default scheduling, kept for A/B runs) and a
     throughput variant (two waves per replicate walking through the bin groups; larger B, or more than 128 epochs).  Same phases, same
@@ -335,13 +335,15 @@ def test_throughput_variant_is_bit_identical(ca, monkeypatch):
         cns[1, 60:] = 0.0        # one whose data stop early (one bin group)
         out = {}
         for variant in ("latency-ilp", "latency", "throughput"):  # (the two latency builds differ in scheduling only)
-            monkeypatch.setenv("COLATE_EM_VARIANT", variant)
-            assert ca.em_kernel_variant(nrep, ep.size) == variant
-            out[variant] = ca.em_batch(grid, csh, cns, ep)
+            ca.em_force_variant(variant)
+            try:
+                assert ca.em_kernel_variant(nrep, ep.size) == variant
+                out[variant] = ca.em_batch(grid, csh, cns, ep)
+            finally:
+                ca.em_force_variant(None)
         for other in ("latency", "throughput"):
             for a, b in zip(out["latency-ilp"], out[other]):
                 assert np.array_equal(a, b)
-    monkeypatch.delenv("COLATE_EM_VARIANT")
     # the library picks the throughput variant by itself for a batch beyond 2 x #CUs: spot-check against the oracle
     ep, _ = ol.epochs_from_bins("3,7,0.2")
     csh, cns = workloads.bootstrap_tables(grid, 600, nb=115, scale=11.0, seed=3)

@@ -121,9 +121,9 @@ for idx, case in enumerate(cases):
         print("epochs", ep, "\ngrid", grid, "\ncsh", csh, "\ncns", cns, "\ninit", init)
         print("oracle: iterations", it0, "flags", fl0, "ll", ll0, "\nkernel: iterations", it1, "flags", fl1, "ll", ll1)
         for v in ("latency-ilp", "latency", "throughput"):
-            os.environ["COLATE_EM_VARIANT"] = v
+            colate_amd.em_force_variant(v)
             print(v, [x.tolist() for x in colate_amd.em_batch(grid, csh, cns, ep, init_rates=init, **kw)[1:3]])
-        del os.environ["COLATE_EM_VARIANT"]
+        colate_amd.em_force_variant(None)
         for mi in (1, 2, 3, 4, 5, 10):
             a = ol.em_batch(grid, csh, cns, ep, init=init, max_iter=mi, min_iter=kw["min_iter"], rel_tol=kw["rel_tol"])
             b = colate_amd.em_batch(grid, csh, cns, ep, init_rates=init, max_iter=mi, min_iter=kw["min_iter"], rel_tol=kw["rel_tol"])
