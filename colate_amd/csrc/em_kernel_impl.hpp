@@ -131,6 +131,23 @@ __device__ __forceinline__ void wave_affine_scan(double& a, double& b, int rows 
 #undef COLATE_AFF_STEP
 }
 
+// inclusive suffix maximum of non-negative values (lane l: max of lanes l..63)
+__device__ __forceinline__ double wave_suffix_max(double v, int lane) {
+  v = __builtin_fmax(v, dpp_d<ROW_SHL1, 0xf, true>(0.0, v));
+  v = __builtin_fmax(v, dpp_d<ROW_SHL2, 0xf, true>(0.0, v));
+  v = __builtin_fmax(v, dpp_d<ROW_SHL4, 0xf, true>(0.0, v));
+  v = __builtin_fmax(v, dpp_d<ROW_SHL8, 0xf, true>(0.0, v));
+  const double r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
+  const double m23 = __builtin_fmax(r2, r3), m123 = __builtin_fmax(r1, m23);
+  const int row = lane >> 4;
+  return __builtin_fmax(v, row == 0 ? m123 : (row == 1 ? m23 : (row == 2 ? r3 : 0.0)));
+}
+// half the spacing of the doubles around z > 0 (0 for z == 0 and below 2^-969): what an addend must reach to change z
+__device__ __forceinline__ double half_ulp_pos(double z) {
+  const int ex = (__double2hiint(z) >> 20) & 0x7ff;  // z = 1.f x 2^(ex - 1023)
+  return ex > 53 ? __hiloint2double((ex - 53) << 20, 0) : 0.0;
+}
+
 #ifdef COLATE_EM_STAMPS
 // diagnostic build only (tools/em_phase_probe.hip): cycle stamps around the phases of an iteration
 __device__ __forceinline__ unsigned long long stamp() {
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       if (kb < 0) kb = 0;  // host validates age >= epochs[0]; never taken
       s_cnt[t] = csh;
       s_cnt[APZ + t] = cns;
-      if (TPUT) s_age[t] = a;
+      s_age[t] = a;  // (throughput variant: per-bin statics; both: the tail model's refresh)
       if (csh > 0 || cns > 0) {
         atomicMin(&s_misc[0], t);
         atomicMax(&s_misc[1], t + 1);
@@ -394,6 +411,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   // epoch-role statics: where the tails of this epoch sit in the compacted tile, and the counts of
   // the bins in LATER epochs (this role's kind)
   int slot0[NCH], slot1[NCH], slot2[NCH], row_x[NCH], row_hi[NCH], seg_hi[NCH];
+  int nlt[NCH];  // bins (compacted positions) in EARLIER epochs: where this epoch's bins start in the compacted order
   double C0[NCH];
   // The reference's denominators contain dt_e * integ with integ = 1 - num[0] - num[1] - ... (coal_EM.cpp:270-274,
   // 445-449): where the mass still to coalesce is below the resolution of that subtraction (survival < ~1e-16:
@@ -409,14 +427,17 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   constexpr double kResolvedRatio = 3.0e10;
   double c_all = 0.0;
   for (int b = 0; b < A; b++) c_all += s_cnt[role * APZ + b];
-  double eta_e[NCH];  // dt_e * residue of this role's bins (0 in the last epoch, which has no dt_e * integ term)
+  // role A: dt_e * residue of the shared bins (0 in the last epoch, which has no dt_e * integ term).  Role B: the tail
+  // model's correction R_e to the not-shared integ mass of the epoch (see `tail model` in P3), refreshed there.
+  double eta_e[NCH];
 #pragma unroll
-  for (int c = 0; c < NCH; c++) eta_e[c] = dt_e[c] * (kIntegResidue * c_all);
+  for (int c = 0; c < NCH; c++) eta_e[c] = (role == 0) ? dt_e[c] * (kIntegResidue * c_all) : 0.0;
+  bool tail_trivial_prev = false;  // (uniform) the last full refresh of the tail model found no epoch in its transition zone
   if (tid < 2 * kWave && lane == 0) s_ll[8 + role] = c_all;  // both kinds' totals, for the epilogue (no register carries them)
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
     const int e = c * kWave + lane;
-    int lo = A, hi = 0;
+    int lo = A, hi = 0, n_before = 0;
     double c_later = 0.0;
     if (ep_on[c]) {
       for (int b = 0; b < A; b++) {
@@ -426,9 +447,11 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           hi = b + 1;
         }
         if (k > e) c_later += s_cnt[role * APZ + b];
+        if (k < e && b >= nzlo && b < nzhi) n_before++;
       }
     }
     C0[c] = c_later;
+    nlt[c] = n_before;
     const int clo = (lo > nzlo ? lo : nzlo) - nzlo, chi = (hi < nzhi ? hi : nzhi) - nzlo;  // compacted, clipped
     seg_hi[c] = chi;
     slot0[c] = slot1[c] = slot2[c] = AP;  // a zero entry
@@ -833,7 +856,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         }
         w[c] = kSteady ? (w0 + w1) : (w0 + w1) + w2;  // (x + 0.0 == x for the non-negative sums here: same bits)
         oN[c] = kSteady ? (n0 + n1) : (n0 + n1) + n2;
-        oD[c] = (kSteady ? (d0 + d1) : (d0 + d1) + d2) + eta_e[c];  // (the residue joins the own-epoch sum: off the scan's dependency chain)
+        oD[c] = (kSteady ? (d0 + d1) : (d0 + d1) + d2);
+        if (ROLE == 0) oD[c] = oD[c] + eta_e[c];  // (the shared residue joins the own-epoch sum: off the scan's dependency chain)
         if (!kSteady && __builtin_expect(more_rows[c], 0)) for (int r = row_x[c]; r <= row_hi[c]; r++) {
           COLATE_COLD();
           int slot = r * 16 + 15;
@@ -910,6 +934,131 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           Tc = readlane_d(Tn, 63);
         }
         COLATE_STAMP(12)
+        // ---- tail model: what the reference's `integ` recurrence makes of the mass beyond t_{e+1}.
+        // For a not-shared bin b the reference normalises its terms n_j = exp(A_j - Z_b) with a log-sum-exp fold over the
+        // epochs (coal_EM.cpp:345-349) and then runs integ = 1 - n_k - n_{k+1} - ... (coal_EM.cpp:445-449).  In IEEE double
+        // (i) a fold step whose increment is below half an ulp of the running value Z_b (|Z_b| ~ cs(age)) leaves it unchanged:
+        // those terms are missing from the normaliser but are still subtracted, so integ_ref = x_be - D_b with D_b the mass
+        // of the absorbed terms (a NEGATIVE bias of ~ulp(cs(age))/2, which accumulates over the iterations in the flat epochs
+        // behind all data); (ii) the clamp `integ > 0 ? integ - n : 0` keeps what is left at >= 0; (iii) the roundings of
+        // the chain (2^-54 per step while integ is in [0.5, 1)) and of the fold (ulp(Z_b)/2 per step) add zero-mean noise of
+        // standard deviation s_b, whose positive part, 0.4 s_b, is what remains once x_be has fallen below D_b:
+        //     integ_ref(b, e) ~ max(x_be - D_b, rho_b),  rho_b = 0.4 s_b,  x_be = S_{e+1} / S(age_b).
+        // Bins are cut (x_be - D_b < rho_b) youngest first, so with tau_b = (D_b + rho_b) S(age_b), made monotone, the cut set
+        // of epoch e is a prefix of the bins and the correction to the exact mass q_e T_e is
+        //     R_e = sum_{cut} c_b (rho_b + D_b) - S_{e+1} sum_{cut} c_b / S(age_b) - [e behind all data] sum_b c_b D_b
+        // from two prefix sums over the bins and one search per epoch.  It moves slowly, so it is refreshed in the first
+        // kTailDense iterations and every kTailEvery-th one after that and held in between (tools/study/residue_models.cpp:
+        // same final rates as the per-iteration evaluation within the reference's own libm-noise spread).
+        {
+          constexpr int kTailDense = 8, kTailEvery = 32, kTailIdle = 128;
+          const bool due = (iter < kTailDense) || ((iter & (kTailEvery - 1)) == 0);
+          if (__builtin_expect(due, 0)) {
+            COLATE_COLD();
+            const int k_old = (int)s_ll[10];  // epoch of the oldest bin with data (-1: none)
+            const int e_o1 = (k_old + 1 < E - 1) ? (k_old + 1 > 0 ? k_old + 1 : 0) : E - 1;
+            const double S_old1 = s_ep[G_S * EPAD + e_o1];  // no bin's S(age) is below this
+            double S1[NCH], We[NCH];
+            unsigned long long between = 0, small_w[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+              const int e = c * kWave + lane;
+              const bool has = e < E - 1;  // (the last epoch has no dt_e * integ term)
+              We[c] = ep_on[c] ? s_ep[G_S * EPAD + e] * p_e[c] : 0.0;  // the fold's term of epoch e per unit S(age)
+              S1[c] = has ? s_ep[G_S * EPAD + e + 1] : 1.0;
+              const double Ie = q_e[c] * T[c];
+              // no bin can be cut while S_{e+1} >= 1e-13 (tau_b <= 3 2^-53 max(cs e^-cs) + chain noise < 3e-16), and sum c D
+              // (<= 1e-16 per unit count) is below 1e-12 of the mass while that is >= 1e-4 per unit count; every bin is cut
+              // once S_{e+1} / S(oldest age) < 2e-17 (rho_b >= 0.4 2^-54)
+              const bool alive = !has || (S1[c] >= 1e-13 && Ie >= 1e-4 * c_all);
+              const bool dead = has && S1[c] < 2e-17 * S_old1;
+              between |= ballot64(!(alive || dead));
+              // a bin absorbs epoch e's term iff W_e / S(age) < ulp(cs(age))/2 <= cs 2^-53, and cs e^-cs <= 1/e
+              small_w[c] = ballot64(ep_on[c] && We[c] < 0x1p-53 * 0.37);
+            }
+            const bool trivial = (between == 0);
+            if (!(trivial && tail_trivial_prev && (iter & (kTailIdle - 1)) != 0)) {
+              tail_trivial_prev = trivial;
+              int e_sm = E;  // first epoch whose term some bin may absorb
+#pragma unroll
+              for (int c = NCH - 1; c >= 0; c--)
+                if (small_w[c]) e_sm = c * kWave + __builtin_ctzll(small_w[c]);
+              double* const s_tau = out_mine + O_W * APZ;  // this role's tile: its tails are in registers by now and the
+              double* const s_PQ = out_mine + O_N * APZ;   // bin waves write it again only behind barriers 3 and 1
+              double* const s_PM = out_mine + O_D * APZ;
+              const int nbt = NB * kWave;
+              double carryQ = 0.0, carryM = 0.0, PDtot = 0.0;
+              for (int g = 0; g < NB; g++) {  // the not-shared bins, youngest group first
+                const int gpos = g * kWave + lane, gbin = nzlo + gpos;
+                const bool inr = gbin < nzhi;
+                const int kbb = inr ? s_kb[inr ? gbin : 0] : E;
+                const double cntb = inr ? s_cnt[APZ + (inr ? gbin : 0)] : 0.0;
+                const bool liveb = inr && cntb > 0 && kbb < E - 1;
+                const int kq = liveb ? kbb : 0;
+                const double ab = liveb ? s_age[gbin] : 0.0, tkb = s_t[kq], tknb = s_t[kq + 1];
+                const double lkb = s_ep[G_LAM * EPAD + kq], ckb = s_ep[G_CS * EPAD + kq];
+                const double csa = ckb + lkb * (ab - tkb);            // cs(age) = -Z_b
+                const double th = half_ulp_pos(csa);                  // what a fold increment must reach to change Z_b
+                const double mb = em::em_exp_t(__builtin_fmin(csa, 230.0), s_exptab);  // 1 / S(age), capped at 1e100
+                double Db = 0.0;
+                int ndrop = 0;
+                for (int e = e_sm; e < E; e++) {  // (uniform; W_e from the epoch lanes of this wave)
+                  double w_s = 0.0;
+#pragma unroll
+                  for (int c = 0; c < NCH; c++)
+                    if (NCH == 1 || (e >> 6) == c) w_s = readlane_d(We[c], e & 63);
+                  const double w = w_s * mb;
+                  const bool dr = (e > kq) && (w < th);
+                  Db += dr ? w : 0.0;
+                  ndrop += dr ? 1 : 0;
+                }
+                const int nfold = E - 1 - kq - ndrop;
+                const double xk = lkb * (tknb - tkb);
+                double nh = (double)(E - kq);  // chain steps taken while integ is still in [0.5, 1): ~ln 2 / (lambda dt)
+                if (xk > 0.0) nh = __builtin_fmin(0.69 / xk, nh);
+                nh += 1.5;
+                const double rho = 0.4 * __builtin_sqrt((0x1p-108 / 3.0) * nh + th * th * ((double)nfold * (1.0 / 3.0)));
+                const double tau = liveb ? (Db + rho) / mb : 0.0;
+                const double cq = liveb ? cntb * (rho + Db) : 0.0, cm = liveb ? cntb * mb : 0.0, cd = liveb ? cntb * Db : 0.0;
+                const double iq = wave_prefix_sum(cq), im = wave_prefix_sum(cm);
+                s_tau[gpos] = tau;
+                s_PQ[gpos] = carryQ + (iq - cq);  // exclusive prefix sums over the bins in age order
+                s_PM[gpos] = carryM + (im - cm);
+                carryQ = carryQ + readlane_d(iq, 63);
+                carryM = carryM + readlane_d(im, 63);
+                PDtot = PDtot + readlane_d(wave_prefix_sum(cd), 63);
+              }
+              // (the totals stay in registers: entry AP of the tile is the tail loads' zero entry and nbt may equal AP)
+              wave_lds_fence();
+              double tau_max = 0.0;
+              for (int g = NB - 1; g >= 0; g--) {  // tau made non-increasing in age order: the cut set is a prefix
+                double tv = wave_suffix_max(s_tau[g * kWave + lane], lane);
+                tv = __builtin_fmax(tv, tau_max);
+                s_tau[g * kWave + lane] = tv;
+                tau_max = readlane_d(tv, 0);
+              }
+              wave_lds_fence();
+#pragma unroll
+              for (int c = 0; c < NCH; c++) {
+                const int e = c * kWave + lane;
+                int bs = 0;  // bins with tau > S_{e+1}
+                if (ballot64(S1[c] < tau_max) != 0) {
+                  for (int step = 256; step >= 1; step >>= 1) {
+                    const int idx = bs + step;
+                    const bool ok = idx <= nbt;
+                    const double tv = s_tau[ok ? idx - 1 : 0];
+                    if (ok && tv > S1[c]) bs = idx;
+                  }
+                }
+                if (bs > nlt[c]) bs = nlt[c];  // (only bins of earlier epochs have a term in this epoch's integ)
+                const bool all_b = bs >= nbt;
+                const double pq = all_b ? carryQ : s_PQ[all_b ? 0 : bs], pm = all_b ? carryM : s_PM[all_b ? 0 : bs];
+                const double R = (pq - S1[c] * pm) - ((e > k_old) ? PDtot : 0.0);
+                eta_e[c] = (ep_on[c] && e < E - 1) ? R : 0.0;
+              }
+            }
+          }
+        }
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           const int e = c * kWave + lane;
@@ -921,7 +1070,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           }
           // later not-shared bins contribute dt_e each, earlier ones their tail mass (last epoch: dt_e = 0 and q_e = 0
           // leave (beta - t p) T, coal_EM.cpp:136-141, without a branch)
-          double dns = dt_e[c] * Cn[c] + ((beta_e[c] - t_e[c] * p_e[c]) * T[c] + dt_e[c] * Gn * (q_e[c] * T[c]));
+          const double integ_ns = __builtin_fmax(Gn * (q_e[c] * T[c]) + eta_e[c], 0.0);  // (eta_e: the tail model's R_e)
+          double dns = dt_e[c] * Cn[c] + ((beta_e[c] - t_e[c] * p_e[c]) * T[c] + dt_e[c] * integ_ns);
           dns = __builtin_fmax(dns, 0.0);
           Dpart[c] = dns + oD[c];
         }

@@ -96,6 +96,23 @@ def main():
                    "replicates_flagging_fewer_epochs_than_checker": int((unres[ok] < unstable[ok]).sum()),
                    "max_extra_epochs_flagged_vs_checker": int((unres[ok] - unstable[ok]).max())},
     }
+    # GPU-vs-oracle difference against the oracle's OWN spread under 1-ulp libm noise, epoch by epoch: the bar for the epochs
+    # outside the 1e-6 claim is "inside the reference's own noise envelope" (a few spreads), wherever the reference is
+    # reproducible at all (spread < 0.3; beyond that its printed value is noise)
+    env = np.maximum(spread, 1e-10)
+    ratio = rel / env
+    repro = (spread < 0.3) & okm
+    per_epoch = []
+    for e in range(E):
+        col = repro[:, e]
+        if col.any() and (spread[col, e].max() > 1e-9 or rel[col, e].max() > 1e-9):
+            per_epoch.append({"epoch": e, "replicates": int(col.sum()), "oracle_spread_median": float(np.median(spread[col, e])),
+                              "gpu_vs_oracle_rel_median": float(np.median(rel[col, e])),
+                              "ratio_median": float(np.median(ratio[col, e])), "ratio_max": float(ratio[col, e].max())})
+    rec["noise_envelope"] = {
+        "what": "gpu_vs_oracle_rel / max(oracle_own_spread_under_libm_noise, 1e-10) over the epochs where the oracle's own spread is below 0.3",
+        "max_ratio": float(ratio[repro].max(initial=0.0)), "entries_above_3": int((ratio[repro] > 3).sum()), "entries": int(repro.sum()),
+        "epochs_with_spread_above_1e-9": per_epoch}
     # what both sides print on the epochs outside the claim (first three replicates that have any)
     outside = []
     for b in np.nonzero(ok & ((unres > 0) | (unstable > 0)))[0][:3]:
@@ -115,6 +132,7 @@ def main():
     os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
     json.dump(rec, open(out_path, "w"), indent=1)
     brief = {k: rec[k] for k in ("config", "iterations", "checker", "kernel")}
+    brief["noise_envelope"] = {k: rec["noise_envelope"][k] for k in ("max_ratio", "entries_above_3", "entries")}
     print(json.dumps(brief), flush=True)
 
 
