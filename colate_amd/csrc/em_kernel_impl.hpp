@@ -528,11 +528,17 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     COLATE_PAD_CASE(4) COLATE_PAD_CASE(5) COLATE_PAD_CASE(6) COLATE_PAD_CASE(7)
 #undef COLATE_PAD_CASE
   }
-  auto iteration = [&](auto role_c, auto leader_c, auto ll_c, auto track_c) __attribute__((always_inline)) -> bool {
+  // The tail model (P3, role B leader) is refreshed in iterations 0, 1, 2, 4, 8, ... (powers of two) and held in between:
+  // its inputs move fast while the rates leave their starting values and ever more slowly afterwards (tools/study/
+  // residue_models.cpp: the final rates stay within the reference's own libm-noise spread of the per-iteration evaluation).
+  auto tail_due = [&](int it) { return (it & (it - 1)) == 0; };
+  auto tail_next_due = [&](int it) { return it <= 1 ? it : (1 << (32 - __builtin_clz((unsigned)(it - 1)))); };  // first due iteration >= it
+  auto iteration = [&](auto role_c, auto leader_c, auto ll_c, auto track_c, auto refresh_c) __attribute__((always_inline)) -> bool {
     COLATE_STAMP(7)
     // (compile-time role / leadership / "no log-likelihood needed" in the steady-state loops below; -1 = run-time value)
     constexpr int kRole = decltype(role_c)::value, kLeader = decltype(leader_c)::value, kNeedLL = decltype(ll_c)::value;
     constexpr int kTrack = decltype(track_c)::value;  // this wave keeps the verdict's history masks (1), does not (0)
+    constexpr int kRefresh = decltype(refresh_c)::value;  // the tail model is refreshed in this iteration (1), is not (0), -1: if due
     constexpr bool kSteady = (kNeedLL >= 0);          // one of the loops compiled per kind of wave: no wave with `more_rows` / `third_row` runs it
     const int ROLE = kRole < 0 ? role : kRole;
     const bool LEADER = kLeader < 0 ? leader : (kLeader != 0);
@@ -947,14 +953,12 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         // Bins are cut (x_be - D_b < rho_b) youngest first, so with tau_b = (D_b + rho_b) S(age_b), made monotone, the cut set
         // of epoch e is a prefix of the bins and the correction to the exact mass q_e T_e is
         //     R_e = sum_{cut} c_b (rho_b + D_b) - S_{e+1} sum_{cut} c_b / S(age_b) - [e behind all data] sum_b c_b D_b
-        // from two prefix sums over the bins and one search per epoch.  It moves slowly, so it is refreshed in the first
-        // kTailDense iterations and every kTailEvery-th one after that and held in between (tools/study/residue_models.cpp:
-        // same final rates as the per-iteration evaluation within the reference's own libm-noise spread).
-        {
-          constexpr int kTailDense = 8, kTailEvery = 32, kTailIdle = 128;
-          const bool due = (iter < kTailDense) || ((iter & (kTailEvery - 1)) == 0);
-          if (__builtin_expect(due, 0)) {
-            COLATE_COLD();
+        // from two prefix sums over the bins and one search per epoch.  It moves slowly, so it is refreshed in iterations
+        // 0, 1, 2, 4, 8, ... only (tail_due above) and held in between.
+        if constexpr (kRefresh != 0) {
+          const bool due = kRefresh > 0 || tail_due(iter);
+          if (__builtin_expect(due, kRefresh > 0)) {
+            if (kRefresh < 0) COLATE_COLD();
             const int k_old = (int)s_ll[10];  // epoch of the oldest bin with data (-1: none)
             const int e_o1 = (k_old + 1 < E - 1) ? (k_old + 1 > 0 ? k_old + 1 : 0) : E - 1;
             const double S_old1 = s_ep[G_S * EPAD + e_o1];  // no bin's S(age) is below this
@@ -967,17 +971,22 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
               We[c] = ep_on[c] ? s_ep[G_S * EPAD + e] * p_e[c] : 0.0;  // the fold's term of epoch e per unit S(age)
               S1[c] = has ? s_ep[G_S * EPAD + e + 1] : 1.0;
               const double Ie = q_e[c] * T[c];
-              // no bin can be cut while S_{e+1} >= 1e-13 (tau_b <= 3 2^-53 max(cs e^-cs) + chain noise < 3e-16), and sum c D
-              // (<= 1e-16 per unit count) is below 1e-12 of the mass while that is >= 1e-4 per unit count; every bin is cut
-              // once S_{e+1} / S(oldest age) < 2e-17 (rho_b >= 0.4 2^-54)
-              const bool alive = !has || (S1[c] >= 1e-13 && Ie >= 1e-4 * c_all);
+              // no bin can be cut while S_{e+1} >= 1e-14 (tau_b <= 3 2^-53 max(cs e^-cs) + chain noise < 3e-16), and sum c D
+              // (<= 1e-16 per unit count) is below 1e-12 of the mass while that is >= 1e-4 per unit count -- in the epochs
+              // behind all data, where the bias accumulates over the iterations (the likelihood is flat in their rates);
+              // in an epoch with data it only shifts the fixed point by that ratio, so 1e-8 per unit count is plenty there;
+              // every bin is cut once S_{e+1} / S(oldest age) < 2e-17 (rho_b >= 0.4 2^-54)
+              // (an epoch without bins in earlier epochs has no such mass at all)
+              const double need = (e > k_old) ? 1e-4 : 1e-8;
+              const bool alive = !has || nlt[c] == 0 || (S1[c] >= 1e-14 && Ie >= need * (c_all - C0[c]));
               const bool dead = has && S1[c] < 2e-17 * S_old1;
               between |= ballot64(!(alive || dead));
               // a bin absorbs epoch e's term iff W_e / S(age) < ulp(cs(age))/2 <= cs 2^-53, and cs e^-cs <= 1/e
-              small_w[c] = ballot64(ep_on[c] && We[c] < 0x1p-53 * 0.37);
+              // (a term of exactly 0 -- an epoch without a valid rate, or underflow -- adds nothing either way)
+              small_w[c] = ballot64(ep_on[c] && We[c] < 0x1p-53 * 0.37 && We[c] > 0.0);
             }
             const bool trivial = (between == 0);
-            if (!(trivial && tail_trivial_prev && (iter & (kTailIdle - 1)) != 0)) {
+            if (!(trivial && tail_trivial_prev && (iter & 255) != 0)) {
               tail_trivial_prev = trivial;
               int e_sm = E;  // first epoch whose term some bin may absorb
 #pragma unroll
@@ -1015,10 +1024,10 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
                 const int nfold = E - 1 - kq - ndrop;
                 const double xk = lkb * (tknb - tkb);
                 double nh = (double)(E - kq);  // chain steps taken while integ is still in [0.5, 1): ~ln 2 / (lambda dt)
-                if (xk > 0.0) nh = __builtin_fmin(0.69 / xk, nh);
+                if (xk > 0.0) nh = __builtin_fmin(0.69 * em::em_rcp(xk), nh);
                 nh += 1.5;
-                const double rho = 0.4 * __builtin_sqrt((0x1p-108 / 3.0) * nh + th * th * ((double)nfold * (1.0 / 3.0)));
-                const double tau = liveb ? (Db + rho) / mb : 0.0;
+                const double rho = 0.4 * __builtin_amdgcn_sqrt((0x1p-108 / 3.0) * nh + th * th * ((double)nfold * (1.0 / 3.0)));
+                const double tau = liveb ? (Db + rho) * em::em_rcp(mb) : 0.0;
                 const double cq = liveb ? cntb * (rho + Db) : 0.0, cm = liveb ? cntb * mb : 0.0, cd = liveb ? cntb * Db : 0.0;
                 const double iq = wave_prefix_sum(cq), im = wave_prefix_sum(cm);
                 s_tau[gpos] = tau;
@@ -1196,10 +1205,26 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     if (n_steady < 0) n_steady = 0;
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
+    using CR = std::integral_constant<int, -1>;
 #define COLATE_STEADY(R, L, T)                                \
   do {                                                        \
-    iteration(R{}, L{}, C0{}, T{});                           \
+    iteration(R{}, L{}, C0{}, T{}, C0{});                     \
   } while (__builtin_expect(++iter < n_steady, 1))
+    // (the role B leader: the iterations that refresh the tail model are peeled out of the hot loop, which then carries
+    // nothing of it but the held correction; same schedule as tail_due())
+#define COLATE_STEADY_B(R, L, T)                                                       \
+  while (iter < n_steady) {                                                            \
+    if (tail_due(iter)) {                                                              \
+      iteration(R{}, L{}, C0{}, T{}, C1{});                                            \
+      if (++iter >= n_steady) break;                                                   \
+    }                                                                                  \
+    int stop_ = tail_next_due(iter);                                                   \
+    if (stop_ > n_steady) stop_ = n_steady;                                            \
+    while (__builtin_expect(iter < stop_, 1)) {                                        \
+      iteration(R{}, L{}, C0{}, T{}, C0{});                                            \
+      ++iter;                                                                          \
+    }                                                                                  \
+  }
     bool any_more_rows = false;
 #pragma unroll
     for (int c = 0; c < NCH; c++) any_more_rows |= more_rows[c];
@@ -1210,10 +1235,28 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     // E = 122, every code placement; profiles/r02_placement.txt) -- there the general loop takes over at min_iter.
 #define COLATE_STEADY_LL(R, L, T)                             \
   for (; iter < max_iter; iter++) {                           \
-    if (iteration(R{}, L{}, C1{}, T{})) {                     \
+    if (iteration(R{}, L{}, C1{}, T{}, C0{})) {               \
       stopped = true;                                         \
       break;                                                  \
     }                                                         \
+  }
+#define COLATE_STEADY_LL_B(R, L, T)                                                    \
+  while (iter < max_iter && !stopped) {                                                \
+    if (tail_due(iter)) {                                                              \
+      if (iteration(R{}, L{}, C1{}, T{}, C1{})) {                                      \
+        stopped = true;                                                                \
+        break;                                                                         \
+      }                                                                                \
+      if (++iter >= max_iter) break;                                                   \
+    }                                                                                  \
+    int stop_ = tail_next_due(iter);                                                   \
+    if (stop_ > max_iter) stop_ = max_iter;                                            \
+    for (; iter < stop_; iter++) {                                                     \
+      if (iteration(R{}, L{}, C1{}, T{}, C0{})) {                                      \
+        stopped = true;                                                                \
+        break;                                                                         \
+      }                                                                                \
+    }                                                                                  \
   }
 #ifndef COLATE_LL_MAX_NCH
 #define COLATE_LL_MAX_NCH 1  // (epoch chunks up to which the log-likelihood-phase loops are compiled, see below)
@@ -1223,11 +1266,20 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   {                                                           \
     if (iter < n_steady) COLATE_STEADY(R, L, T);              \
   }
+#define COLATE_BOTH_B(R, L, T)                                \
+  {                                                           \
+    COLATE_STEADY_B(R, L, T)                                  \
+  }
 #else
 #define COLATE_BOTH(R, L, T)                                  \
   {                                                           \
     if (iter < n_steady) COLATE_STEADY(R, L, T);              \
     if constexpr (NCH <= COLATE_LL_MAX_NCH) COLATE_STEADY_LL(R, L, T) \
+  }
+#define COLATE_BOTH_B(R, L, T)                                \
+  {                                                           \
+    COLATE_STEADY_B(R, L, T)                                  \
+    if constexpr (NCH <= COLATE_LL_MAX_NCH) COLATE_STEADY_LL_B(R, L, T) \
   }
 #endif
     if (!(any_more_rows || third_row)) {
@@ -1247,21 +1299,23 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         }
       } else {
         if (leader) {
-          COLATE_BOTH(C1, C1, C0)
+          COLATE_BOTH_B(C1, C1, C0)
         } else {
           COLATE_BOTH(C1, C0, C0)
         }
       }
     }
+#undef COLATE_BOTH_B
 #undef COLATE_BOTH
+#undef COLATE_STEADY_LL_B
 #undef COLATE_STEADY_LL
+#undef COLATE_STEADY_B
 #undef COLATE_STEADY
     // ... and where the per-kind loops of that phase are not built (more than 64 epochs), one loop compiled for "log-likelihood
     // needed" only: no cost for the steady loops, 2.20 -> 2.08 us per iteration at E = 122
     if constexpr (NCH > COLATE_LL_MAX_NCH) if (!(any_more_rows || third_row)) {
-      using CR = std::integral_constant<int, -1>;
       for (; iter < max_iter; iter++) {
-        if (iteration(CR{}, CR{}, C1{}, CR{})) {
+        if (iteration(CR{}, CR{}, C1{}, CR{}, CR{})) {
           stopped = true;
           break;
         }
@@ -1269,8 +1323,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     }
   }
   for (; !stopped && iter < max_iter; iter++) {
-    using CR = std::integral_constant<int, -1>;
-    if (iteration(CR{}, CR{}, CR{}, CR{})) break;
+    using CRt = std::integral_constant<int, -1>;
+    if (iteration(CRt{}, CRt{}, CRt{}, CRt{}, CRt{})) break;
   }
 
 #ifdef COLATE_EM_STAMPS

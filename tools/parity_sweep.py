@@ -108,7 +108,8 @@ def main():
         if col.any() and (spread[col, e].max() > 1e-9 or rel[col, e].max() > 1e-9):
             per_epoch.append({"epoch": e, "replicates": int(col.sum()), "oracle_spread_median": float(np.median(spread[col, e])),
                               "gpu_vs_oracle_rel_median": float(np.median(rel[col, e])),
-                              "ratio_median": float(np.median(ratio[col, e])), "ratio_max": float(ratio[col, e].max())})
+                              "ratio_median": float(np.median(ratio[col, e])), "ratio_p90": float(np.percentile(ratio[col, e], 90)),
+                              "ratio_max": float(ratio[col, e].max())})
     rec["noise_envelope"] = {
         "what": "gpu_vs_oracle_rel / max(oracle_own_spread_under_libm_noise, 1e-10) over the epochs where the oracle's own spread is below 0.3",
         "max_ratio": float(ratio[repro].max(initial=0.0)), "entries_above_3": int((ratio[repro] > 3).sum()), "entries": int(repro.sum()),

@@ -30,7 +30,7 @@ static double half_ulp(double z) {  // half the spacing of doubles at |z|
 }
 
 struct M5Bin { int b, k; double c, cs_a, xk; };
-static int REFRESH = 32, EARLY = 0;
+static int REFRESH = 32, EARLY = 0, POW2 = 0;
 struct Fact {
   int E, A, model, iter_no = 0;
   std::vector<M5Bin> m5_bins;
@@ -143,7 +143,7 @@ struct Fact {
       }
     }
     // ---- model 5 = the algorithm of the HIP kernel (refresh every REFRESH iterations, R5 held in between)
-    if (model == 5 && ((iter_no % REFRESH) == 0 || iter_no < EARLY)) {
+    if (model == 5 && (POW2 ? (iter_no < EARLY || ((iter_no & (iter_no - 1)) == 0) || (iter_no % REFRESH) == 0) : ((iter_no % REFRESH) == 0 || iter_no < EARLY))) {
       int k_old = -1;
       for (auto& bn : m5_bins) if (bn.k > k_old) k_old = bn.k;
       // epochs whose fold term can be absorbed by some bin / whose survival can be below some bin's threshold
@@ -257,6 +257,7 @@ int main(int argc, char** argv) {
   if (argc > 6) S0 = atof(argv[6]);
   if (getenv("REFRESH")) REFRESH = atoi(getenv("REFRESH"));
   if (getenv("EARLY")) EARLY = atoi(getenv("EARLY"));
+  if (getenv("POW2")) POW2 = atoi(getenv("POW2"));
   for (int m = 0; m <= 5; m++) {
     F.model = m;
     std::vector<double> rates(E, 1.0 / 20000.0);
