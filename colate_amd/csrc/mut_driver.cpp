@@ -16,8 +16,13 @@
 #include <signal.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -139,6 +144,14 @@ void print_help() {
             << std::endl;
 }
 
+// ------------------------------------------------------------------ stage timing (COLATE_TIMING=1: one stderr line at the end)
+struct StageTimes {
+  double parse_mut = 0, table_fill = 0, wait_for_parser = 0, bootstrap_em = 0;
+  bool on = std::getenv("COLATE_TIMING") != nullptr;
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+StageTimes g_times;
+
 // ------------------------------------------------------------------ gz text
 // igzstream semantics of the reference: zlib reads gzip and plain files alike.
 class GzText {
@@ -193,53 +206,166 @@ struct MutRow {
   std::exit(1);
 }
 
+// std::stoi on the text at p (leading white space, sign, digits; what follows the digits is ignored), without the copy
+// and the exceptions: false where std::stoi would throw (no digits, or out of int range)
+inline bool parse_stoi(const char* p, const char* end, int& out, const char** after = nullptr) {
+  while (p < end && (*p == ' ' || (*p >= '\t' && *p <= '\r'))) p++;
+  bool neg = false;
+  if (p < end && (*p == '+' || *p == '-')) neg = (*p++ == '-');
+  if (p >= end || *p < '0' || *p > '9') return false;
+  long long v = 0;
+  while (p < end && *p >= '0' && *p <= '9') {
+    v = v * 10 + (*p++ - '0');
+    if (v > 2147483648LL) return false;
+  }
+  if (neg) v = -v;
+  if (v > 2147483647LL || v < -2147483648LL) return false;
+  out = (int)v;
+  if (after) *after = p;
+  return true;
+}
+// std::stof: strtof (the field ends at a ';' or at the terminating NUL of the line buffer, where strtof stops by itself)
+inline bool parse_stof(const char* p, float& out) {
+  char* e = nullptr;
+  errno = 0;
+  const float v = std::strtof(p, &e);
+  if (e == p || errno == ERANGE) return false;
+  out = v;
+  return true;
+}
+
+// One row from the NUL-terminated line [b, e): the fields parse_tmptmp looks at (mutations.cpp:77-246)
+inline bool parse_mut_line(char* b, char* e, MutRow& r) {
+  // the first ten ';' of the line (snp;pos;dist;rs;tree;branches;is_not_mapping;is_flipped;age_begin;age_end;<rest>)
+  char* sep[11];
+  int ns = 0;
+  for (char* q = b; q < e && ns < 11; q++)
+    if (*q == ';') sep[ns++] = q;
+  if (ns < 10) return false;  // needs 10 separators
+  int tmp;
+  if (!parse_stoi(b, sep[0], tmp)) return false;
+  if (!parse_stoi(sep[0] + 1, sep[1], r.pos)) return false;
+  if (!parse_stoi(sep[1] + 1, sep[2], tmp)) return false;
+  if (!parse_stoi(sep[3] + 1, sep[4], tmp)) return false;
+  r.num_branches = 0;
+  for (const char* q = sep[4] + 1; q < sep[5];) {  // white-space separated branch indices, each through stoi
+    while (q < sep[5] && (*q == ' ' || (*q >= '\t' && *q <= '\r'))) q++;
+    if (q >= sep[5]) break;
+    const char* tok_end = q;
+    while (tok_end < sep[5] && !(*tok_end == ' ' || (*tok_end >= '\t' && *tok_end <= '\r'))) tok_end++;
+    if (!parse_stoi(q, tok_end, tmp)) return false;
+    r.num_branches++;
+    q = tok_end;
+  }
+  if (!parse_stoi(sep[6] + 1, sep[7], r.flipped)) return false;
+  *sep[8] = 0;  // (strtof must not read past its field: "1e5;2" is fine, but keep it strict)
+  const bool ok1 = parse_stof(sep[7] + 1, r.age_begin);
+  *sep[8] = ';';
+  *sep[9] = 0;
+  const bool ok2 = parse_stof(sep[8] + 1, r.age_end);
+  *sep[9] = ';';
+  if (!ok1 || !ok2) return false;
+  // field 10: up to the next ';' or the end of the line; "NA" is kept when it is empty and the last field
+  char* f10_end = (ns >= 11) ? sep[10] : e;
+  if (f10_end > sep[9] + 1 || ns >= 11)
+    r.mutation_type.assign(sep[9] + 1, f10_end);
+  else
+    r.mutation_type = "NA";
+  return true;
+}
+
 bool read_mut_file(const std::string& filename, std::vector<MutRow>& rows) {
-  GzText is;
-  if (!is.open(filename) && !is.open(filename + ".gz")) {
+  gzFile f = gzopen(filename.c_str(), "rb");
+  if (!f) f = gzopen((filename + ".gz").c_str(), "rb");
+  if (!f) {
     std::cerr << "Error while reading " << filename << "(.gz)." << std::endl;
     std::exit(1);  // mutations.cpp:265-268
   }
-  std::string line;
-  is.getline(line);  // header
+  gzbuffer(f, 1 << 20);
   rows.clear();
-  std::vector<std::string> f;
-  while (is.getline(line)) {
-    // split on ';' (the reference walks the same separators field by field)
-    f.clear();
-    size_t start = 0;
+  // inflate in 4 MB pieces and cut lines in place (no per-line std::string, no per-field copies)
+  std::vector<char> buf((4u << 20) + 1);
+  size_t have = 0;
+  bool header_done = false, eof = false;
+  while (!eof) {
+    if (have == buf.size() - 1) buf.resize(buf.size() * 2);  // a line longer than the buffer
+    const int got = gzread(f, buf.data() + have, (unsigned)(buf.size() - 1 - have));
+    if (got <= 0) eof = true;
+    else have += (size_t)got;
+    char* b = buf.data();
+    char* const end = b + have;
     for (;;) {
-      size_t sc = line.find(';', start);
-      if (sc == std::string::npos) {
-        f.push_back(line.substr(start));
-        break;
+      char* nl = static_cast<char*>(std::memchr(b, '\n', (size_t)(end - b)));
+      if (!nl) {
+        if (!eof || b == end) break;
+        nl = end;  // last line without a newline
       }
-      f.push_back(line.substr(start, sc - start));
-      start = sc + 1;
-    }
-    if (f.size() < 11) mut_line_error(line);  // ...;age_begin;age_end;<rest> needs 10 separators
-    MutRow r;
-    try {
-      (void)std::stoi(f[0]);
-      r.pos = std::stoi(f[1]);
-      (void)std::stoi(f[2]);
-      (void)std::stoi(f[4]);
-      std::istringstream bs(f[5]);
-      std::string tok;
-      while (bs >> tok) {
-        (void)std::stoi(tok);
-        r.num_branches++;
+      *nl = 0;
+      if (!header_done) {
+        header_done = true;
+      } else {
+        rows.emplace_back();
+        if (!parse_mut_line(b, nl, rows.back())) mut_line_error(std::string(b, nl));
       }
-      r.flipped = std::stoi(f[7]);
-      r.age_begin = std::stof(f[8]);
-      r.age_end = std::stof(f[9]);
-    } catch (...) {
-      mut_line_error(line);
+      b = (nl < end) ? nl + 1 : end;
+      if (b >= end) break;
     }
-    if (!f[10].empty() || f.size() > 11) r.mutation_type = f[10];
-    rows.push_back(r);
+    have = (size_t)(end - b);
+    if (have) std::memmove(buf.data(), b, have);
   }
+  gzclose(f);
   return true;
 }
+
+// Reader thread: inflates and tokenises the .mut files in order, at most two chromosomes ahead of the table fill.  The
+// fill itself has to stay sequential -- every sampled age is a draw from the run's one std::mt19937 (coal.cpp:2262, 2282),
+// so the order of the draws is part of the result -- but nothing of the parsing depends on it.
+class MutPrefetcher {
+ public:
+  explicit MutPrefetcher(std::vector<std::string> files) : files_(std::move(files)) {
+    worker_ = std::thread([this] {
+      for (const std::string& f : files_) {
+        std::vector<MutRow> rows;
+        const double t0 = StageTimes::now();
+        read_mut_file(f, rows);
+        const double dt = StageTimes::now() - t0;
+        std::unique_lock<std::mutex> lk(m_);
+        parse_seconds_ += dt;
+        cv_.wait(lk, [this] { return q_.size() < 2 || stop_; });
+        if (stop_) return;
+        q_.push_back(std::move(rows));
+        cv_.notify_all();
+      }
+    });
+  }
+  ~MutPrefetcher() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    if (worker_.joinable()) worker_.join();
+  }
+  void next(std::vector<MutRow>& rows) {  // the next file's rows, in the order given
+    const double t0 = StageTimes::now();
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [this] { return !q_.empty(); });
+    rows = std::move(q_.front());
+    q_.pop_front();
+    g_times.wait_for_parser += StageTimes::now() - t0;
+    g_times.parse_mut = parse_seconds_;
+    cv_.notify_all();
+  }
+
+ private:
+  std::vector<std::string> files_;
+  std::thread worker_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<std::vector<MutRow>> q_;
+  double parse_seconds_ = 0;
+  bool stop_ = false;
+};
 
 // data.cpp:213-235: sequence = upper-cased lines after the header, concatenated
 void read_fasta_mask(const std::string& filename, std::string& seq) {
@@ -327,6 +453,8 @@ int fill_tables_from_tmp(const std::vector<std::string>& chr_names,
 
   std::vector<MutRow> rows_local;
   std::string tar_mask, ref_mask, ancestral, derived;
+  std::unique_ptr<MutPrefetcher> prefetch;
+  if (!mut_cache) prefetch.reset(new MutPrefetcher(mut_files));
   for (size_t chr = 0; chr < mut_files.size(); chr++) {
     std::cerr << "parsing CHR: " << chr + 1 << " / " << mut_files.size() << std::endl;
     // --pairs: every (target, reference) pair walks the same .mut rows; parse each file once
@@ -339,9 +467,10 @@ int fill_tables_from_tmp(const std::vector<std::string>& chr_names,
       }
       rows_p = &it->second;
     } else {
-      read_mut_file(mut_files[chr], rows_local);
+      prefetch->next(rows_local);
     }
     const std::vector<MutRow>& rows = *rows_p;
+    const double t_fill0 = StageTimes::now();
     if (has_tar_mask) read_fasta_mask(target_masks[chr], tar_mask);
     if (has_ref_mask) read_fasta_mask(ref_masks[chr], ref_mask);
     int current_block_base = 0;
@@ -437,6 +566,7 @@ int fill_tables_from_tmp(const std::vector<std::string>& chr_names,
       }
     }
     advance_block();  // chromosome end, coal.cpp:2306-2310
+    g_times.table_fill += StageTimes::now() - t_fill0;
   }
   if (tgt.fp) std::fclose(tgt.fp);
   if (ref.fp) std::fclose(ref.fp);
@@ -671,7 +801,16 @@ int run_mut(const Options& opt) {
   if (opt.has("counts_out") && !gpu_bootstrap) {
     if (g_rank.rank == 0) write_counts();
   }
-  if (opt.has("counts_only")) return 0;
+  auto report_times = [&]() {
+    if (g_times.on)
+      std::cerr << "Timing: parse_mut " << g_times.parse_mut << " s (on the reader thread when pipelined), table_fill "
+                << g_times.table_fill << " s, waited_for_parser " << g_times.wait_for_parser << " s, bootstrap_em "
+                << g_times.bootstrap_em << " s" << std::endl;
+  };
+  if (opt.has("counts_only")) {
+    report_times();
+    return 0;
+  }
 
   // ---- epochs (coal.cpp:3501-3646)
   std::vector<double> epochs(COLATE_MAX_EPOCHS), init_rates(COLATE_MAX_EPOCHS, COLATE_DEFAULT_INIT_RATE);
@@ -705,6 +844,7 @@ int run_mut(const Options& opt) {
   std::vector<double> rates((size_t)B * E), ll(B);
   std::vector<int> iters(B), flags(B);
   int rc;
+  const double t_em0 = StageTimes::now();
   if (g_rank.ranked) {
     // one process per GPU: this rank's contiguous replicate range on its own device, then ONE RCCL all-gather
     if (const char* h = std::getenv("COLATE_TEST_HANG_RANK")) {  // test hook: a rank stuck as if inside a collective
@@ -774,6 +914,8 @@ int run_mut(const Options& opt) {
                          COLATE_DEFAULT_REL_TOL, COLATE_DEFAULT_RATE_FLOOR, rates.data(),
                          iters.data(), ll.data(), flags.data());
   }
+  g_times.bootstrap_em = StageTimes::now() - t_em0;
+  report_times();
   if (rc) {
     std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
     return 1;

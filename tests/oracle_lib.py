@@ -165,6 +165,16 @@ def stable_mask(grid, csh, cns, epochs, rates0, rtol=1e-8, **kw):
     return mask_from_reruns(rates0, noise + scaled, rtol)
 
 
+def noise_envelope(r_gpu, r0, noise_reruns, floor=1e-10):
+    """GPU-vs-oracle relative difference in units of the oracle's OWN spread under 1-ulp libm noise (rerun_rates()[0]),
+    per (replicate, epoch): (ratio, spread).  Outside the 1e-6 claim the bar is "inside the reference's noise envelope":
+    a few spreads wherever the reference is reproducible at all (spread well below 1)."""
+    r_gpu, r0 = np.atleast_2d(r_gpu), np.atleast_2d(r0)
+    den = np.maximum(np.abs(r0), 1e-300)
+    spread = np.max([np.abs(np.atleast_2d(n) - r0) for n in noise_reruns], axis=0) / den
+    return (np.abs(r_gpu - r0) / den) / np.maximum(spread, floor), spread
+
+
 def check_rates(r_gpu, flags, r0, mask, rtol=1e-6):
     """The two parity statements of the GPU tests, per replicate:
     (1) on every epoch the checker finds stable (stable_mask) the GPU rate equals the oracle's within rtol;

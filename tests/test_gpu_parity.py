@@ -101,11 +101,19 @@ def test_em_matches_oracle_122_epochs(ca):
     r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep)
     assert (it0 == it1).all() and (ca.status_flags(fl1) == 0).all()
     assert np.allclose(ll1, ll0, rtol=1e-12, atol=0)
-    mask = ol.stable_mask(grid, csh, cns, ep, r0)
+    noise, scaled = ol.rerun_rates(grid, csh, cns, ep)
+    mask = ol.mask_from_reruns(r0, noise + scaled)
     unres, unstable = ol.check_rates(r1, fl1, r0, mask, RATE_RTOL)
     # only the far tail is undetermined in the reference: 104+ of 122 epochs are pinned (measured: 105-106), and the
-    # kernel flags that tail itself -- never fewer epochs than the checker finds unstable, at most 3 more
-    assert (unstable <= 18).all() and (unres >= unstable).all() and (unres <= unstable + 3).all(), (unres, unstable)
+    # kernel flags that tail itself: the checker's count +- 1 (its own count moves by one between noise seeds), at most 2 more
+    assert (unstable <= 18).all() and (unres >= unstable - 1).all() and (unres <= unstable + 2).all(), (unres, unstable)
+    # ... and inside that tail the kernel stays within the reference's own noise envelope wherever the reference is
+    # reproducible at all: the kernel models what IEEE arithmetic makes of the reference's `integ` recurrence (absorbed
+    # log-sum-exp terms, the clamp, rounding noise).  Measured over 32 whole-genome replicates
+    # (profiles/parity/): median ratio ~1, 90th percentile 2.3, maximum 5.5 with the spread estimated from three reruns.
+    ratio, spread = ol.noise_envelope(r1, r0, noise)
+    zone = (spread > 1e-9) & (spread < 0.05)
+    assert zone.sum() >= 9 and np.median(ratio[zone]) <= 3.0 and ratio[zone].max() <= 12.0, (np.median(ratio[zone]), ratio[zone].max())
 
 
 @pytest.mark.parametrize("bins,E_expect", [("3,7,0.3", 17), ("3,7,0.1", 43), ("3,7,0.07", 61), ("2,7.95,0.03", 202),
