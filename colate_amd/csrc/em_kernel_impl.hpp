@@ -58,6 +58,9 @@ namespace {
 constexpr int kWave = 64;
 enum { O_W = 0, O_N, O_D, kNumBinArrays };  // per-bin values -> epochs: weight (c r | c u), own-epoch num, denom
 enum { G_LAM = 0, G_INV, G_XA, G_P, G_BETA, G_CS, G_S, G_PW, kNumGather };  // per-epoch values in LDS
+constexpr int G_Q = kNumGather;  // one more row, q_e, only with two or more epoch chunks (the split leaders of em_kernel hand it over)
+constexpr int num_gather_rows(int nch) { return nch >= 2 ? kNumGather + 1 : kNumGather; }
+constexpr int tail_scratch_arrays(int nch) { return nch >= 2 ? 3 : 0; }  // with chunks split over waves the tail model's refresh cannot borrow the tile
 
 // ----------------------------------------------------------------- lane plumbing
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -264,14 +267,16 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   // ---- LDS carve-up ----
   double* s_t = lds;                                 // [EPAD + 1] epoch starts
   double* s_ep = s_t + EPAD + 1;                     // [kNumGather][EPAD] epoch values (A writes CS,S,PW; B the rest)
-  double* s_out = s_ep + kNumGather * EPAD;          // [2 roles][kNumBinArrays][APZ] per-bin tails
+  constexpr int kRows = num_gather_rows(NCH);
+  double* s_out = s_ep + kRows * EPAD;               // [2 roles][kNumBinArrays][APZ] per-bin tails
   double* s_nd = s_out + 2 * kNumBinArrays * APZ;    // [2 roles][2][EPAD] partial N, D per role
   double* s_cfail = s_nd + 4 * EPAD;                 // [2 roles][APZ] counts of bins whose normaliser failed
   double* s_cnt = s_cfail + 2 * APZ;                 // [2 roles][APZ] counts
   double* s_ll = s_cnt + 2 * APZ;                    // [8] per-wave log-likelihood partials + [2] total counts per kind + oldest data epoch
   double* s_exptab = s_ll + 12;                      // [64] 2^(j/32) as hi, lo pairs for em::em_exp_t (em_math.hpp)
-  double* s_age = s_exptab + em::kExpTableDoubles;   // [AP] age grid (throughput variant)
-  int* s_kb = reinterpret_cast<int*>(s_age + AP);    // [AP + 1] epoch of each bin
+  double* s_age = s_exptab + em::kExpTableDoubles;   // [AP] age grid (throughput variant; the tail model's refresh)
+  double* s_tscr = s_age + AP;                       // [3][APZ] scratch of the tail model's refresh (two or more epoch chunks only)
+  int* s_kb = reinterpret_cast<int*>(s_tscr + tail_scratch_arrays(NCH) * APZ);  // [AP + 1] epoch of each bin
   int* s_fail = s_kb + AP + 1;                       // [8] per-wave "a bin failed" flags
   int* s_misc = s_fail + 8;                          // [4] nzlo, nzhi, flags
   int* s_bflags = s_misc + 4;                        // [AP] packed per-position statics (throughput variant)
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   // ------------------------------------------------------------------ prologue
   const double* epochs = p.epochs + (size_t)rep * p.epochs_stride;
   for (int i = tid; i < EPAD + 1; i += blockDim.x) s_t[i] = (i < E) ? epochs[i] : 0.0;
-  for (int i = tid; i < kNumGather * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ; i += blockDim.x) s_ep[i] = 0.0;
+  for (int i = tid; i < kRows * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ; i += blockDim.x) s_ep[i] = 0.0;
   if (tid == 0) {
     s_misc[0] = A;
     s_misc[1] = 0;
@@ -543,7 +548,14 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     constexpr int kRefresh = decltype(refresh_c)::value;  // the tail model is refreshed in this iteration (1), is not (0), -1: if due
     constexpr bool kSteady = (kNeedLL >= 0);          // one of the loops compiled per kind of wave: no wave with `more_rows` / `third_row` runs it
     const int ROLE = kRole < 0 ? role : kRole;
+    // kLeader: 0 no epoch work; 1 (or the run-time `leader`): every chunk of epochs; 2 / 3: the 65..128-epoch SPLIT -- this
+    // wave owns chunk 0 / chunk 1 of its role's epoch work and the wave of the other bin group owns the other one (both
+    // run the M-step for all chunks; the carries across the chunk boundary are recomputed locally, in the same order)
     const bool LEADER = kLeader < 0 ? leader : (kLeader != 0);
+    constexpr bool kSplit = (kLeader >= 2);
+    constexpr int kOwn = (kLeader == 3) ? 1 : 0;
+    static_assert(!kSplit || NCH == 2, "the chunk split is for two chunks");
+    auto own = [&](int c) { return !kSplit || c == kOwn; };
     const bool need_ll = kNeedLL < 0 ? ((MODE == 1) || (iter >= p.min_iter) || (iter == max_iter - 1)) : (kNeedLL != 0);
     // ============================================================ P1: epoch values (ROLE leaders)
     double q_e[NCH], p_e[NCH], beta_e[NCH], S_e[NCH], omS_e[NCH], cs_e[NCH], csn_e[NCH];
@@ -558,13 +570,16 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         double carry = 0.0;
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
+          if (kSplit && c > kOwn) break;  // (the owner of chunk 1 scans chunk 0 too: it needs the carry)
 #if COLATE_ABL_HAS(11)
           const double incl = x_e[c] * 7.0;
 #else
           const double incl = wave_prefix_sum(x_e[c], erows);
 #endif
-          cs_e[c] = carry + dpp_d<WAVE_SHR1, 0xf, true>(0.0, incl);
-          csn_e[c] = cs_e[c] + x_e[c];
+          if (own(c)) {
+            cs_e[c] = carry + dpp_d<WAVE_SHR1, 0xf, true>(0.0, incl);
+            csn_e[c] = cs_e[c] + x_e[c];
+          }
           carry = carry + readlane_d(incl, 63);
         }
       }
@@ -572,6 +587,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       if (ROLE == 0) {
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
+          if (!own(c)) continue;
           const int e = c * kWave + lane;
 #if COLATE_ABL_HAS(3)
           S_e[c] = 1.0 - cs_e[c] * 1e-3;
@@ -588,6 +604,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       } else {
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
+          if (!own(c)) continue;
           const int e = c * kWave + lane;
 #if COLATE_ABL_HAS(7)
           const double inv = 2.0e4 - lam_e[c];
@@ -616,6 +633,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #endif
           s_ep[G_P * EPAD + e] = p_e[c];
           s_ep[G_BETA * EPAD + e] = beta_e[c];
+          if (NCH >= 2) s_ep[G_Q * EPAD + e] = q_e[c];  // (the other chunk's owner needs it for the carry of the affine scan; the tail model)
         }
       }
     }
@@ -846,19 +864,30 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       const int anyf = s_fail[ROLE];  // (four bytes: this role's bin groups)
       double w[NCH], oN[NCH], oD[NCH];
 #pragma unroll
+      for (int c = 0; c < NCH; c++) w[c] = oN[c] = oD[c] = 0.0;
+#pragma unroll
       for (int c = 0; c < NCH; c++) {
+        // split: besides its own chunk a wave needs the weights (only) of the chunk its scan's carry comes from -- the
+        // later chunk for role A's suffix sums, the earlier one for role B's forward recurrence
+        const bool mine = own(c);
+        const bool for_carry = kSplit && !mine && (kRole == 0 ? c > kOwn : c < kOwn);
+        if (!mine && !for_carry) continue;
 #if COLATE_ABL_HAS(1)  // ablation: no tail loads
         const double w0 = 1e-3 * lane, w1 = 0, w2 = 0, n0 = 1e-3, n1 = 0, n2 = 0, d0 = 1.0, d1 = 0, d2 = 0;
 #else
         const double w0 = out_mine[O_W * APZ + slot0[c]], w1 = out_mine[O_W * APZ + slot1[c]];
-        const double n0 = out_mine[O_N * APZ + slot0[c]], n1 = out_mine[O_N * APZ + slot1[c]];
-        const double d0 = out_mine[O_D * APZ + slot0[c]], d1 = out_mine[O_D * APZ + slot1[c]];
         // (a run of equal-epoch bins reaching into a third row: never in a wave that runs a steady-state loop; adding
         // the zero entry there would give the same sums)
-        const double w2 = kSteady ? 0.0 : out_mine[O_W * APZ + slot2[c]], n2 = kSteady ? 0.0 : out_mine[O_N * APZ + slot2[c]];
-        const double d2 = kSteady ? 0.0 : out_mine[O_D * APZ + slot2[c]];
+        const double w2 = kSteady ? 0.0 : out_mine[O_W * APZ + slot2[c]];
+        double n0 = 0, n1 = 0, n2 = 0, d0 = 0, d1 = 0, d2 = 0;
+        if (mine) {
+          n0 = out_mine[O_N * APZ + slot0[c]], n1 = out_mine[O_N * APZ + slot1[c]];
+          d0 = out_mine[O_D * APZ + slot0[c]], d1 = out_mine[O_D * APZ + slot1[c]];
+          n2 = kSteady ? 0.0 : out_mine[O_N * APZ + slot2[c]];
+          d2 = kSteady ? 0.0 : out_mine[O_D * APZ + slot2[c]];
+        }
 #endif
-        if (ROLE == 0) {  // the shared leader also needs the not-shared leader's p_e, beta_e
+        if (ROLE == 0 && mine) {  // the shared leader also needs the not-shared leader's p_e, beta_e
           p_e[c] = s_ep[G_P * EPAD + c * kWave + lane];
           beta_e[c] = s_ep[G_BETA * EPAD + c * kWave + lane];
         }
@@ -900,17 +929,21 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         double cR = 0.0;
 #pragma unroll
         for (int c = NCH - 1; c >= 0; c--) {
+          RSn[c] = 0.0;
+          if (kSplit && c < kOwn) continue;  // (the owner of chunk 0 sums chunk 1 too: it needs the carry)
 #if COLATE_ABL_HAS(9)
           const double sR = w[c] * 3.0;
 #else
           const double sR = wave_suffix_sum(w[c], lane, erows);
 #endif
-          RSn[c] = cR + dpp_d<WAVE_SHL1, 0xf, true>(0.0, sR);
+          if (own(c)) RSn[c] = cR + dpp_d<WAVE_SHL1, 0xf, true>(0.0, sR);
           cR = cR + readlane_d(sR, 0);
         }
         COLATE_STAMP(11)
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
+          Npart[c] = Dpart[c] = 0.0;
+          if (!own(c)) continue;
           const int e = c * kWave + lane;
           const double W = S_e[c] * p_e[c];                    // exp(A_ep)
           const double VW = S_e[c] * beta_e[c] - t_e[c] * W;   // exp(B_ep) - t_e exp(A_ep)
@@ -933,6 +966,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         double Tc = 0.0;
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
+          T[c] = 0.0;
+          if (kSplit && c > kOwn) break;  // (the owner of chunk 1 runs chunk 0's recurrence too: it needs the carry)
+          if (kSplit && !own(c)) q_e[c] = s_ep[G_Q * EPAD + c * kWave + lane];  // (the other owner's value, same bits)
           double a = ep_on[c] ? q_e[c] : 1.0, b = ep_on[c] ? w[c] : 0.0;
 #if !COLATE_ABL_HAS(9)
           wave_affine_scan(a, b, erows);
@@ -970,9 +1006,13 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
             for (int c = 0; c < NCH; c++) {
               const int e = c * kWave + lane;
               const bool has = e < E - 1;  // (the last epoch has no dt_e * integ term)
-              We[c] = ep_on[c] ? s_ep[G_S * EPAD + e] * p_e[c] : 0.0;  // the fold's term of epoch e per unit S(age)
+              // (split: the other chunk's p_e comes from the row its owner has written; the same bits as that owner's register)
+              const double pe = (kSplit && !own(c)) ? s_ep[G_P * EPAD + e] : p_e[c];
+              We[c] = ep_on[c] ? s_ep[G_S * EPAD + e] * pe : 0.0;  // the fold's term of epoch e per unit S(age)
               S1[c] = has ? s_ep[G_S * EPAD + e + 1] : 1.0;
-              const double Ie = q_e[c] * T[c];
+              // mass beyond t_{e+1} per unit count of the earlier bins: exact with one chunk; with more, where a wave may
+              // own one chunk only, its lower bound S_{e+1} (every 1 / S(age) >= 1), so that all owners decide alike
+              const double Ie = (NCH == 1) ? q_e[c] * T[c] : S1[c] * (c_all - C0[c]);
               // no bin can be cut while S_{e+1} >= 1e-14 (tau_b <= 3 2^-53 max(cs e^-cs) + chain noise < 3e-16), and sum c D
               // (<= 1e-16 per unit count) is below 1e-12 of the mass while that is >= 1e-4 per unit count -- in the epochs
               // behind all data, where the bias accumulates over the iterations (the likelihood is flat in their rates);
@@ -994,9 +1034,12 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #pragma unroll
               for (int c = NCH - 1; c >= 0; c--)
                 if (small_w[c]) e_sm = c * kWave + __builtin_ctzll(small_w[c]);
-              double* const s_tau = out_mine + O_W * APZ;  // this role's tile: its tails are in registers by now and the
-              double* const s_PQ = out_mine + O_N * APZ;   // bin waves write it again only behind barriers 3 and 1
-              double* const s_PM = out_mine + O_D * APZ;
+              // scratch: with one chunk this role's tile (its tails are in registers by now and the bin waves write it again
+              // only behind barriers 3 and 1); with more chunks the owners of a role run this refresh side by side (same
+              // inputs, same values) while the other may still be loading its tails, so it has arrays of its own
+              double* const s_tau = (NCH == 1) ? out_mine + O_W * APZ : s_tscr;
+              double* const s_PQ = (NCH == 1) ? out_mine + O_N * APZ : s_tscr + APZ;
+              double* const s_PM = (NCH == 1) ? out_mine + O_D * APZ : s_tscr + 2 * APZ;
               const int nbt = NB * kWave;
               double carryQ = 0.0, carryM = 0.0, PDtot = 0.0;
               for (int g = 0; g < NB; g++) {  // the not-shared bins, youngest group first
@@ -1072,6 +1115,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         }
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
+          Npart[c] = Dpart[c] = 0.0;
+          if (!own(c)) continue;
           const int e = c * kWave + lane;
           Npart[c] = p_e[c] * T[c] + oN[c];
           double Gn = 1.0;  // mass still to coalesce after t_{e+1}, relative to survival there
@@ -1089,6 +1134,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       }
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
+        if (!own(c)) continue;
         s_nd[(ROLE * 2 + 0) * EPAD + c * kWave + lane] = Npart[c];
         s_nd[(ROLE * 2 + 1) * EPAD + c * kWave + lane] = Dpart[c];
       }
@@ -1284,9 +1330,25 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     if constexpr (NCH <= COLATE_LL_MAX_NCH) COLATE_STEADY_LL_B(R, L, T) \
   }
 #endif
+    using C2 = std::integral_constant<int, 2>;
+    using C3 = std::integral_constant<int, 3>;
+    // 65..128 epochs with at least two bin groups: the epoch work of a role is SPLIT over its first two waves, chunk 0 to the
+    // wave of bin group 0 and chunk 1 to that of bin group 1 (which otherwise sits out P1 and P3); any_more_rows / third_row
+    // are properties of a wave's OWN epochs' tail slots, so the choice must be the same in all four: it is made on NB alone
+    // and a wave that cannot run a steady loop makes all of them fall back (s_misc is the only channel: not worth it --
+    // such tables, an epoch spanning > 32 bins with data at > 64 epochs, do not occur with the reference's grids).
+    const bool split = (NCH == 2) && !TPUT && NB >= 2;
     if (!(any_more_rows || third_row)) {
       if (role == 0) {  // (the wave that keeps the verdict's history is of role 0: wave 0 or wave 2)
-        if (leader) {
+        if (split && grp <= 1) {
+          if constexpr (NCH == 2) {
+            if (grp == 0) {
+              COLATE_BOTH(C0, C2, C0)
+            } else {
+              COLATE_BOTH(C0, C3, C1)  // (wave 2: the tracker whenever NB >= 2)
+            }
+          }
+        } else if (leader) {
           if (tracker) {
             COLATE_BOTH(C0, C1, C1)
           } else {
@@ -1300,7 +1362,15 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           }
         }
       } else {
-        if (leader) {
+        if (split && grp <= 1) {
+          if constexpr (NCH == 2) {
+            if (grp == 0) {
+              COLATE_BOTH_B(C1, C2, C0)
+            } else {
+              COLATE_BOTH_B(C1, C3, C0)
+            }
+          }
+        } else if (leader) {
           COLATE_BOTH_B(C1, C1, C0)
         } else {
           COLATE_BOTH(C1, C0, C0)
@@ -1443,7 +1513,8 @@ inline size_t em_lds_bytes(int E, int A) {
   const size_t EPAD = (size_t)em_chunks(E) * kWave;
   const size_t AP = (size_t)em_groups(A) * kWave;
   const size_t APZ = AP + 2;
-  const size_t doubles = (EPAD + 1) + kNumGather * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ + 12 + em::kExpTableDoubles + AP;
+  const size_t doubles = (EPAD + 1) + num_gather_rows(em_chunks(E)) * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ + 12 +
+                         em::kExpTableDoubles + AP + tail_scratch_arrays(em_chunks(E)) * APZ;
   const size_t ints = (AP + 1) + 8 + 4 + AP;
   return doubles * sizeof(double) + ints * sizeof(int);
 }
