@@ -24,7 +24,7 @@
 //
 // with age bins one per lane (compacted to the bins that carry data: NB groups of
 // 64, so 2*NB waves; waves without bins retire before the loop, which keeps the
-// s_barrier cheap), epoch e in lane e & 63 (chunk e >> 6) of the role leaders,
+// s_barrier cheap), epoch e in lane e / NCH (slot e % NCH; NCH = 1, 2, 4 for up to 64, 128, 256 epochs) of the role leaders,
 // and three workgroup barriers per iteration (epoch values -> bins -> per-epoch
 // sums -> rates).  Per-epoch sums of the per-bin terms are reduced in registers
 // (row-segmented DPP) and handed over through an LDS tile at static "tail" slots.
@@ -259,6 +259,12 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   const int AP = NBMAX * kWave;       // >= A
   const int APZ = AP + 2;             // stride of the per-bin tiles; entry AP stays zero (the "no tail" slot)
   const int tid = threadIdx.x, lane = tid & 63;
+  // Epoch e lives in lane e / NCH, slot e % NCH of the epoch-level waves: the NCH epochs of a lane are CONSECUTIVE, so a
+  // scan over the epochs is one wave scan of the lanes' totals plus NCH - 1 local steps (round 2 kept chunks of 64
+  // consecutive epochs per slot -- one wave scan per chunk -- and 65..128 epochs cost two of every scan)
+  constexpr int kSlotShift = (NCH == 1) ? 0 : (NCH == 2 ? 1 : 2);
+  static_assert(NCH == 1 || NCH == 2 || NCH == 4, "NCH");
+  auto ep_of = [&](int c) { return lane * NCH + c; };
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (a scalar: branches on role / group / wave are s_cbranch_scc)
   const int role = wave & 1;          // 0: shared (A), 1: not shared (B)
   const int grp = wave >> 1;          // waves 2g, 2g+1 own bin group g: the live waves are 0..2*NB-1, one per SIMD
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   bool vstat[NCH], ep_on[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
-    const int e = c * kWave + lane;
+    const int e = ep_of(c);
     ep_on[c] = e < E;
     t_e[c] = s_t[e];
     tn_e[c] = 0.0;
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   if (tid < 2 * kWave && lane == 0) s_ll[8 + role] = c_all;  // both kinds' totals, for the epilogue (no register carries them)
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
-    const int e = c * kWave + lane;
+    const int e = ep_of(c);
     int lo = A, hi = 0, n_before = 0;
     double c_later = 0.0;
     if (ep_on[c]) {
@@ -496,19 +502,22 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   int my_flags = 0;
   // bit l: the numerator of epoch l of the chunk was below kTinyNum (0 included) / was not 0 in some iteration
   constexpr double kTinyNum = 1e-280;
-  unsigned long long ever_tiny[NCH], ever_nonzero[NCH];
+  // (kept per lane in vector registers -- the smallest and the largest high word the numerator has had, one instruction
+  // each per iteration -- and turned into the lane masks in the epilogue: as scalar masks updated by ballots the history
+  // cost the wave that keeps it 460 cycles per iteration at two epochs per lane, most of it spill traffic of the masks)
+  unsigned tr_min[NCH], tr_max[NCH];
+  int tr_noisy = 0;
 #pragma unroll
-  for (int c = 0; c < NCH; c++) ever_tiny[c] = ever_nonzero[c] = 0;
+  for (int c = 0; c < NCH; c++) tr_min[c] = 0xffffffffu, tr_max[c] = 0u;
   // any epoch (up to the oldest data) whose rate was, in some iteration, a quotient with a denominator below kNoisyRatio residues (and neither a
   // copy nor clamped to the floor): the reference's own trajectory is then rounding noise of >= 1e-4 per iteration there
   // (its integ residue, see kResolvedRatio) -- harmless for epochs that converge to a fixed point, decisive for the
   // flat epochs behind all data, whose final value records the history (epilogue)
   constexpr double kNoisyRatio = 1.0e6;
-  unsigned long long ever_noisy = 0;
   double noisy_thr[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; c++)  // (only epochs up to the oldest bin with data: the flat ones behind it do not move at all)
-    noisy_thr[c] = (double)(c * kWave + lane) <= s_ll[10] ? kNoisyRatio * (dt_e[c] * (kIntegResidue * (s_ll[8] + s_ll[9]))) : 0.0;
+    noisy_thr[c] = (double)(ep_of(c)) <= s_ll[10] ? kNoisyRatio * (dt_e[c] * (kIntegResidue * (s_ll[8] + s_ll[9]))) : 0.0;
   unsigned long long prev_fail = 0;
   unsigned long long ep_mask[NCH];  // the lanes of each chunk that hold an epoch
 #pragma unroll
@@ -548,47 +557,47 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     constexpr int kRefresh = decltype(refresh_c)::value;  // the tail model is refreshed in this iteration (1), is not (0), -1: if due
     constexpr bool kSteady = (kNeedLL >= 0);          // one of the loops compiled per kind of wave: no wave with `more_rows` / `third_row` runs it
     const int ROLE = kRole < 0 ? role : kRole;
-    // kLeader: 0 no epoch work; 1 (or the run-time `leader`): every chunk of epochs; 2 / 3: the 65..128-epoch SPLIT -- this
-    // wave owns chunk 0 / chunk 1 of its role's epoch work and the wave of the other bin group owns the other one (both
-    // run the M-step for all chunks; the carries across the chunk boundary are recomputed locally, in the same order)
+    // kLeader: 0 no epoch work; 1 (or the run-time `leader`): all epochs; 2 / 3: the 65..128-epoch SPLIT -- this wave owns
+    // slot 0 / slot 1 (the even / the odd epochs) of its role's epoch work and the wave of the other bin group owns the other
+    // one (both run the M-step and the scans for all epochs: same operations, same bits)
     const bool LEADER = kLeader < 0 ? leader : (kLeader != 0);
     constexpr bool kSplit = (kLeader >= 2);
     constexpr int kOwn = (kLeader == 3) ? 1 : 0;
-    static_assert(!kSplit || NCH == 2, "the chunk split is for two chunks");
+    static_assert(!kSplit || NCH == 2, "the split is for two epochs per lane");
     auto own = [&](int c) { return !kSplit || c == kOwn; };
     const bool need_ll = kNeedLL < 0 ? ((MODE == 1) || (iter >= p.min_iter) || (iter == max_iter - 1)) : (kNeedLL != 0);
     // ============================================================ P1: epoch values (ROLE leaders)
-    double q_e[NCH], p_e[NCH], beta_e[NCH], S_e[NCH], omS_e[NCH], cs_e[NCH], csn_e[NCH];
+    double q_e[NCH], p_e[NCH], beta_e[NCH], S_e[NCH], omS_e[NCH], cs_e[NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; c++) q_e[c] = p_e[c] = beta_e[c] = S_e[c] = omS_e[c] = cs_e[c] = csn_e[c] = 0.0;
+    for (int c = 0; c < NCH; c++) q_e[c] = p_e[c] = beta_e[c] = S_e[c] = omS_e[c] = cs_e[c] = 0.0;
     if (LEADER && !COLATE_ABL_HAS(15)) {
       double x_e[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; c++) x_e[c] = lam_e[c] * dt_e[c];
       if (ROLE == 0) {
-        // cs_e = sum_{j<e} lambda_j dt_j (coal_EM.cpp:100-103), as a wave scan
-        double carry = 0.0;
+        // cs_e = sum_{j<e} lambda_j dt_j (coal_EM.cpp:100-103): a lane's epochs are consecutive, so one wave scan of the
+        // lanes' totals plus the local prefix (split: every owner runs it in full -- the rates of all epochs are in every
+        // wave -- and keeps its own slot)
+        double loc[NCH];
+        loc[0] = 0.0;
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-          if (kSplit && c > kOwn) break;  // (the owner of chunk 1 scans chunk 0 too: it needs the carry)
+        for (int c = 1; c < NCH; c++) loc[c] = loc[c - 1] + x_e[c - 1];
+        const double tot = loc[NCH - 1] + x_e[NCH - 1];
 #if COLATE_ABL_HAS(11)
-          const double incl = x_e[c] * 7.0;
+        const double incl = tot * 7.0;
 #else
-          const double incl = wave_prefix_sum(x_e[c], erows);
+        const double incl = wave_prefix_sum(tot, erows);
 #endif
-          if (own(c)) {
-            cs_e[c] = carry + dpp_d<WAVE_SHR1, 0xf, true>(0.0, incl);
-            csn_e[c] = cs_e[c] + x_e[c];
-          }
-          carry = carry + readlane_d(incl, 63);
-        }
+        const double excl = dpp_d<WAVE_SHR1, 0xf, true>(0.0, incl);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) cs_e[c] = excl + loc[c];
       }
       COLATE_STAMP(8)
       if (ROLE == 0) {
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           if (!own(c)) continue;
-          const int e = c * kWave + lane;
+          const int e = ep_of(c);
 #if COLATE_ABL_HAS(3)
           S_e[c] = 1.0 - cs_e[c] * 1e-3;
           omS_e[c] = cs_e[c] * 1e-3;
@@ -605,7 +614,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           if (!own(c)) continue;
-          const int e = c * kWave + lane;
+          const int e = ep_of(c);
 #if COLATE_ABL_HAS(7)
           const double inv = 2.0e4 - lam_e[c];
 #else
@@ -647,9 +656,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       const int kq = bs0.kb < E ? bs0.kb : 0;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
-        const int lo = __builtin_amdgcn_ds_bpermute((kq & 63) << 2, __double2loint(lam_e[c]));
-        const int hi = __builtin_amdgcn_ds_bpermute((kq & 63) << 2, __double2hiint(lam_e[c]));
-        if (NCH == 1 || (kq >> 6) == c) lk_pre = __hiloint2double(hi, lo);
+        const int lo = __builtin_amdgcn_ds_bpermute(((kq >> kSlotShift) & 63) << 2, __double2loint(lam_e[c]));
+        const int hi = __builtin_amdgcn_ds_bpermute(((kq >> kSlotShift) & 63) << 2, __double2hiint(lam_e[c]));
+        if (NCH == 1 || (kq & (NCH - 1)) == c) lk_pre = __hiloint2double(hi, lo);
       }
       asm volatile("" : "+v"(lk_pre));  // (keeps the fetch on this side of the barrier)
     }
@@ -663,7 +672,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     // first thing behind barrier 1 in role B's waves)
     bool absorbing = false;
     {
-      const int cl = (E - 1) >> 6, ll_ = (E - 1) & 63;
+      const int cl = (E - 1) & (NCH - 1), ll_ = (E - 1) >> kSlotShift;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         const unsigned long long pos = ballot64(lam_e[c] > 0.0);
@@ -867,11 +876,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       for (int c = 0; c < NCH; c++) w[c] = oN[c] = oD[c] = 0.0;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
-        // split: besides its own chunk a wave needs the weights (only) of the chunk its scan's carry comes from -- the
-        // later chunk for role A's suffix sums, the earlier one for role B's forward recurrence
+        // split: besides its own slot's three sums a wave needs the weights (only) of the other slot's epochs: its scan
+        // runs over all epochs
         const bool mine = own(c);
-        const bool for_carry = kSplit && !mine && (kRole == 0 ? c > kOwn : c < kOwn);
-        if (!mine && !for_carry) continue;
 #if COLATE_ABL_HAS(1)  // ablation: no tail loads
         const double w0 = 1e-3 * lane, w1 = 0, w2 = 0, n0 = 1e-3, n1 = 0, n2 = 0, d0 = 1.0, d1 = 0, d2 = 0;
 #else
@@ -888,8 +895,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         }
 #endif
         if (ROLE == 0 && mine) {  // the shared leader also needs the not-shared leader's p_e, beta_e
-          p_e[c] = s_ep[G_P * EPAD + c * kWave + lane];
-          beta_e[c] = s_ep[G_BETA * EPAD + c * kWave + lane];
+          p_e[c] = s_ep[G_P * EPAD + ep_of(c)];
+          beta_e[c] = s_ep[G_BETA * EPAD + ep_of(c)];
         }
         w[c] = kSteady ? (w0 + w1) : (w0 + w1) + w2;  // (x + 0.0 == x for the non-negative sums here: same bits)
         oN[c] = kSteady ? (n0 + n1) : (n0 + n1) + n2;
@@ -916,7 +923,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
           for (int c = 0; c < NCH; c++) {
             double fs = 0.0;
             for (int q = seg_hi[c] > 0 ? seg_hi[c] : 0; ep_on[c] && q < nzhi - nzlo; q++) {
-              if (s_kb[nzlo + q] > c * kWave + lane) fs += s_cfail[ROLE * APZ + q];
+              if (s_kb[nzlo + q] > ep_of(c)) fs += s_cfail[ROLE * APZ + q];
             }
             Cn[c] -= fs;
           }
@@ -925,26 +932,27 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       double Npart[NCH], Dpart[NCH];
       if (ROLE == 0) {
         // RS = sum c r over the shared bins of LATER epochs (suffix sums over epochs)
-        double RSn[NCH];
-        double cR = 0.0;
+        double RSn[NCH], ls[NCH];
+        ls[NCH - 1] = 0.0;
 #pragma unroll
-        for (int c = NCH - 1; c >= 0; c--) {
-          RSn[c] = 0.0;
-          if (kSplit && c < kOwn) continue;  // (the owner of chunk 0 sums chunk 1 too: it needs the carry)
+        for (int c = NCH - 2; c >= 0; c--) ls[c] = ls[c + 1] + w[c + 1];
+        {
+          const double tot = ls[0] + w[0];
 #if COLATE_ABL_HAS(9)
-          const double sR = w[c] * 3.0;
+          const double sR = tot * 3.0;
 #else
-          const double sR = wave_suffix_sum(w[c], lane, erows);
+          const double sR = wave_suffix_sum(tot, lane, erows);
 #endif
-          if (own(c)) RSn[c] = cR + dpp_d<WAVE_SHL1, 0xf, true>(0.0, sR);
-          cR = cR + readlane_d(sR, 0);
+          const double excl = dpp_d<WAVE_SHL1, 0xf, true>(0.0, sR);
+#pragma unroll
+          for (int c = 0; c < NCH; c++) RSn[c] = excl + ls[c];
         }
         COLATE_STAMP(11)
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           Npart[c] = Dpart[c] = 0.0;
           if (!own(c)) continue;
-          const int e = c * kWave + lane;
+          const int e = ep_of(c);
           const double W = S_e[c] * p_e[c];                    // exp(A_ep)
           const double VW = S_e[c] * beta_e[c] - t_e[c] * W;   // exp(B_ep) - t_e exp(A_ep)
           const double PWn = omS_e[c] + W;                     // sum_{j<=e} exp(A_ep[j])
@@ -963,19 +971,28 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         // forward recurrence T_{e+1} = q_e T_e + h_e, T_0 = 0
         // (T_e = sum over not-shared bins b in EARLIER epochs of c_b u_b/Sig_b * S_e/S_{k_b+1})
         double T[NCH];
-        double Tc = 0.0;
+        {
+          // a lane's map T -> T after its epochs, composed locally; one wave scan of the lanes' maps; the local steps again
+          double qa[NCH], wb[NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-          T[c] = 0.0;
-          if (kSplit && c > kOwn) break;  // (the owner of chunk 1 runs chunk 0's recurrence too: it needs the carry)
-          if (kSplit && !own(c)) q_e[c] = s_ep[G_Q * EPAD + c * kWave + lane];  // (the other owner's value, same bits)
-          double a = ep_on[c] ? q_e[c] : 1.0, b = ep_on[c] ? w[c] : 0.0;
+          for (int c = 0; c < NCH; c++) {
+            if (kSplit && !own(c)) q_e[c] = s_ep[G_Q * EPAD + ep_of(c)];  // (the other owner's value, same bits)
+            qa[c] = ep_on[c] ? q_e[c] : 1.0;
+            wb[c] = ep_on[c] ? w[c] : 0.0;
+          }
+          double a = qa[0], b = wb[0];
+#pragma unroll
+          for (int c = 1; c < NCH; c++) {
+            b = em::fma_(qa[c], b, wb[c]);
+            a = a * qa[c];
+          }
 #if !COLATE_ABL_HAS(9)
           wave_affine_scan(a, b, erows);
 #endif
-          const double Tn = em::fma_(a, Tc, b);         // T_{e+1}
-          T[c] = dpp_d<WAVE_SHR1, 0xf, false>(Tc, Tn);  // T_e (lane 0: carry-in)
-          Tc = readlane_d(Tn, 63);
+          // (b of lane l: T after the epochs of lanes 0..l, starting from T = 0)
+          T[0] = dpp_d<WAVE_SHR1, 0xf, true>(0.0, b);  // T at the lane's first epoch (lane 0: 0)
+#pragma unroll
+          for (int c = 1; c < NCH; c++) T[c] = em::fma_(qa[c - 1], T[c - 1], wb[c - 1]);
         }
         COLATE_STAMP(12)
         // ---- tail model: what the reference's `integ` recurrence makes of the mass beyond t_{e+1}.
@@ -1004,7 +1021,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
             unsigned long long between = 0, small_w[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
-              const int e = c * kWave + lane;
+              const int e = ep_of(c);
               const bool has = e < E - 1;  // (the last epoch has no dt_e * integ term)
               // (split: the other chunk's p_e comes from the row its owner has written; the same bits as that owner's register)
               const double pe = (kSplit && !own(c)) ? s_ep[G_P * EPAD + e] : p_e[c];
@@ -1032,8 +1049,11 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
               tail_trivial_prev = trivial;
               int e_sm = E;  // first epoch whose term some bin may absorb
 #pragma unroll
-              for (int c = NCH - 1; c >= 0; c--)
-                if (small_w[c]) e_sm = c * kWave + __builtin_ctzll(small_w[c]);
+              for (int c = 0; c < NCH; c++)
+                if (small_w[c]) {
+                  const int e1 = __builtin_ctzll(small_w[c]) * NCH + c;
+                  e_sm = e1 < e_sm ? e1 : e_sm;
+                }
               // scratch: with one chunk this role's tile (its tails are in registers by now and the bin waves write it again
               // only behind barriers 3 and 1); with more chunks the owners of a role run this refresh side by side (same
               // inputs, same values) while the other may still be loading its tails, so it has arrays of its own
@@ -1060,7 +1080,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
                   double w_s = 0.0;
 #pragma unroll
                   for (int c = 0; c < NCH; c++)
-                    if (NCH == 1 || (e >> 6) == c) w_s = readlane_d(We[c], e & 63);
+                    if (NCH == 1 || (e & (NCH - 1)) == c) w_s = readlane_d(We[c], e >> kSlotShift);
                   const double w = w_s * mb;
                   const bool dr = (e > kq) && (w < th);
                   Db += dr ? w : 0.0;
@@ -1094,7 +1114,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
               wave_lds_fence();
 #pragma unroll
               for (int c = 0; c < NCH; c++) {
-                const int e = c * kWave + lane;
+                const int e = ep_of(c);
                 int bs = 0;  // bins with tau > S_{e+1}
                 if (ballot64(S1[c] < tau_max) != 0) {
                   for (int step = 256; step >= 1; step >>= 1) {
@@ -1117,7 +1137,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         for (int c = 0; c < NCH; c++) {
           Npart[c] = Dpart[c] = 0.0;
           if (!own(c)) continue;
-          const int e = c * kWave + lane;
+          const int e = ep_of(c);
           Npart[c] = p_e[c] * T[c] + oN[c];
           double Gn = 1.0;  // mass still to coalesce after t_{e+1}, relative to survival there
           if (__builtin_expect(!absorbing, 0)) {
@@ -1135,8 +1155,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         if (!own(c)) continue;
-        s_nd[(ROLE * 2 + 0) * EPAD + c * kWave + lane] = Npart[c];
-        s_nd[(ROLE * 2 + 1) * EPAD + c * kWave + lane] = Dpart[c];
+        s_nd[(ROLE * 2 + 0) * EPAD + ep_of(c)] = Npart[c];
+        s_nd[(ROLE * 2 + 1) * EPAD + ep_of(c)] = Dpart[c];
       }
     }
     COLATE_STAMP(4)
@@ -1146,7 +1166,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     double N_e[NCH], D_e[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-      const int e = c * kWave + lane;
+      const int e = ep_of(c);
       N_e[c] = s_nd[0 * EPAD + e] + s_nd[2 * EPAD + e];
       D_e[c] = s_nd[1 * EPAD + e] + s_nd[3 * EPAD + e];
       if (MODE == 1 && ep_on[c]) {  // (EM mode: a NaN sticks to the rate and is flagged at the end)
@@ -1164,8 +1184,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           if (ep_on[c]) {
-            p.out_num[(size_t)rep * E + c * kWave + lane] = N_e[c];
-            p.out_den[(size_t)rep * E + c * kWave + lane] = D_e[c];
+            p.out_num[(size_t)rep * E + ep_of(c)] = N_e[c];
+            p.out_den[(size_t)rep * E + ep_of(c)] = D_e[c];
           }
         }
       }
@@ -1176,9 +1196,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       double cand[NCH];
       bool self[NCH];  // this lane's epoch keeps its own quotient (does not copy)
       unsigned long long keep[NCH];  // epochs that do NOT copy their predecessor
-      // the copying epochs form a prefix 0..m-1 (they all become 0) unless a bit of `bad` is set: as scalar mask
-      // arithmetic, so that one compare and one branch decide
-      unsigned long long bad = 0, lower_keep = 0;  // lower_keep: all ones once an earlier chunk holds a keeper
+      unsigned long long cpm[NCH];   // epochs that do
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         const bool copy = (N_e[c] == 0);
@@ -1194,17 +1212,26 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         // (the compare's own lane mask and the static mask of the live epoch lanes: scalar arithmetic from here on)
         const unsigned long long zero_n = __builtin_amdgcn_fcmp(N_e[c], 0.0, 1 /* FCMP_OEQ */);
         keep[c] = ep_mask[c] & ~zero_n;
-        const unsigned long long cp = ep_mask[c] & zero_n;
+        cpm[c] = ep_mask[c] & zero_n;
         self[c] = ep_on[c] && !copy;
-        bad |= (cp & (cp + 1ull)) | (lower_keep & cp);
-        lower_keep |= keep[c] ? ~0ull : 0ull;
+      }
+      // The copying epochs form a prefix 0..m-1 of the epoch order (they all become 0 then) unless a bit of `bad` is set: as
+      // scalar mask arithmetic, so that one compare and one branch decide.  With NCH consecutive epochs per lane that is: every
+      // slot's copying lanes are a prefix of the lanes, the prefixes do not grow with the slot, and slot 0's is at most one
+      // lane longer than the last slot's.
+      unsigned long long bad = cpm[0] & ~((cpm[NCH - 1] << 1) | 1ull);
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        bad |= cpm[c] & (cpm[c] + 1ull);
+        if (c > 0) bad |= cpm[c] & ~cpm[c - 1];
       }
       if (kTrack < 0 ? tracker : (kTrack != 0)) {  // scalar masks for the epilogue's verdict, kept by a wave that has time for it
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-          ever_tiny[c] |= ballot64(ep_on[c] && !(N_e[c] >= kTinyNum));
-          ever_nonzero[c] |= ballot64(ep_on[c] && N_e[c] != 0.0);
-          ever_noisy |= ballot64(ep_on[c] && N_e[c] != 0.0 && D_e[c] < noisy_thr[c] && cand[c] > p.rate_floor);
+          const unsigned nh = (unsigned)__double2hiint(N_e[c]);  // (N >= 0: the high words order like the values)
+          tr_min[c] = nh < tr_min[c] ? nh : tr_min[c];
+          tr_max[c] = nh > tr_max[c] ? nh : tr_max[c];
+          tr_noisy |= (ep_on[c] && N_e[c] != 0.0 && D_e[c] < noisy_thr[c] && cand[c] > p.rate_floor) ? 1 : 0;
         }
       }
       if (__builtin_expect(bad == 0, 1)) {
@@ -1212,22 +1239,23 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
         for (int c = 0; c < NCH; c++) lam_e[c] = self[c] ? cand[c] : 0.0;
       } else {
         COLATE_COLD();
-        // num == 0: take the (already updated) rate of the previous epoch, 0 if there is none
+        // num == 0: take the (already updated) rate of the previous epoch, 0 if there is none: the quotient of the nearest
+        // earlier epoch that keeps its own -- in this lane's earlier slots, else the last one of the nearest lane below
+        unsigned long long any_keep = 0;
+        double lastc = 0.0;
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-          const unsigned long long below = keep[c] & ((1ull << lane) - 1ull);
-          const int src = below ? 63 - __builtin_clzll(below) : 0;
-          const double from_chunk = __shfl(cand[c], src, 64);
-          double from_lower = 0.0;  // nearest keeper in an earlier chunk (uniform)
-          bool have_lower = false;
+          any_keep |= keep[c];
+          lastc = self[c] ? cand[c] : lastc;
+        }
+        const unsigned long long below = any_keep & ((1ull << lane) - 1ull);
+        const int src = below ? 63 - __builtin_clzll(below) : 0;
+        const double from_lanes = __shfl(lastc, src, 64);
+        double prev = below ? from_lanes : 0.0;
 #pragma unroll
-          for (int cc = NCH - 1; cc >= 0; cc--) {
-            if (cc < c && !have_lower && keep[cc]) {
-              from_lower = readlane_d(cand[cc], 63 - __builtin_clzll(keep[cc]));
-              have_lower = true;
-            }
-          }
-          lam_e[c] = ep_on[c] ? (self[c] ? cand[c] : (below ? from_chunk : from_lower)) : 0.0;
+        for (int c = 0; c < NCH; c++) {
+          lam_e[c] = ep_on[c] ? (self[c] ? cand[c] : prev) : 0.0;
+          prev = self[c] ? cand[c] : prev;
         }
       }
     }
@@ -1332,11 +1360,11 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
 #endif
     using C2 = std::integral_constant<int, 2>;
     using C3 = std::integral_constant<int, 3>;
-    // 65..128 epochs with at least two bin groups: the epoch work of a role is SPLIT over its first two waves, chunk 0 to the
-    // wave of bin group 0 and chunk 1 to that of bin group 1 (which otherwise sits out P1 and P3); any_more_rows / third_row
-    // are properties of a wave's OWN epochs' tail slots, so the choice must be the same in all four: it is made on NB alone
-    // and a wave that cannot run a steady loop makes all of them fall back (s_misc is the only channel: not worth it --
-    // such tables, an epoch spanning > 32 bins with data at > 64 epochs, do not occur with the reference's grids).
+    // 65..128 epochs with at least two bin groups: the epoch work of a role is SPLIT over its first two waves -- the even
+    // epochs (slot 0 of every lane) to the wave of bin group 0, the odd ones (slot 1) to that of bin group 1, which otherwise
+    // sits out P1 and P3.  Each owner runs the (single) scans in full -- they need all epochs -- and the per-epoch work
+    // (exp, the N and D terms, the stores) for its own slot: per wave about what one chunk of 64 epochs costs.
+    // any_more_rows / third_row are functions of the epochs' bin spans only, the same in every wave, so all four choose alike.
     const bool split = (NCH == 2) && !TPUT && NB >= 2;
     if (!(any_more_rows || third_row)) {
       if (role == 0) {  // (the wave that keeps the verdict's history is of role 0: wave 0 or wave 2)
@@ -1400,8 +1428,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   }
 
 #ifdef COLATE_EM_STAMPS
-  if (p.out_num && lane == 0 && MODE == 0 && leader) {  // diagnostic build: per-role phase cycles in place of out_num
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out_num) + ((size_t)rep * 4 + role) * 16;
+  if (p.out_num && lane == 0 && MODE == 0 && wave < 4) {  // diagnostic build: per-wave phase cycles in place of out_num
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out_num) + ((size_t)rep * 4 + wave) * 16;
     for (int i = 0; i < 16; i++) dbg[i] = st_acc[i];
   }
 #endif
@@ -1427,11 +1455,12 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     // residue and the rate sits on the floor, the floor is what every build prints.  The count of such trailing epochs
     // goes out in the high bits of out_flags (COLATE_FLAG_UNRESOLVED, COLATE_UNRESOLVED_EPOCHS()).
     int first_bad = E;
+    const unsigned long long ever_noisy = ballot64(tr_noisy != 0);
     const int n_evals = s_misc[3];  // (read before this wave stores the verdict there)
     constexpr int kMinEvals = 32;
 #pragma unroll
     for (int c = NCH - 1; c >= 0; c--) {
-      const int e = c * kWave + lane;
+      const int e = ep_of(c);
       const double D = s_nd[1 * EPAD + e] + s_nd[3 * EPAD + e];  // denominators of the last E-step
       const double Nfin = s_nd[0 * EPAD + e] + s_nd[2 * EPAD + e];
       const double eta = dt_e[c] * (kIntegResidue * (s_ll[8] + s_ll[9]));  // dt_e * residue of ALL bins (both kinds); 0 in the last epoch and beyond E
@@ -1441,7 +1470,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       // reach zero (the reference's exp(A_e - Z_b) per bin, the kernel's W_e RS_e and q_e T_e chains).  So an epoch whose
       // numerator was ever within a factor 1e-280 of that edge while not being a structural zero (0 in every iteration,
       // like epoch 0) is not reproducible.
-      const bool snapshot = ((ever_tiny[c] >> lane) & 1ull) && ((ever_nonzero[c] >> lane) & 1ull);
+      // (high words: below kTinyNum up to its last 32 bits; not 0 = at least 2^-1042)
+      const bool snapshot = ep_on[c] && tr_min[c] < (unsigned)__double2hiint(kTinyNum) && tr_max[c] != 0u;
       // An epoch that starts after the oldest bin with data: every contribution to its statistics has num/denom equal to
       // the current rate (the likelihood does not depend on it), so the EM leaves it where it is -- normally at its starting
       // value, which every build prints alike.  If it has moved, rounding moved it (early iterations far from the optimum),
@@ -1453,7 +1483,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       // on the way, and where one of those was ever a quotient of rounding residue (ever_noisy) the reference's path is its
       // own (measured: sparse tables, the last epoch with data overshoots x4 on the reference, its survival underflows and
       // the flat epoch behind it ends as a copy, while the exact sums never come near; profiles/parity/sweep2_sparse_*).
-      const bool path_dependent = (double)e > s_ll[10] && ever_noisy != 0;
+      const bool path_dependent = (double)e > s_ll[10] && ever_noisy != 0;  // (any lane, any slot)
       // "Denominator nothing but residue, rate on the floor" is what every build prints only if the reference's own residue
       // cannot be so much smaller than the modelled one that its quotient leaves the floor: the model is an average over
       // the (bin, kind) pairs it evaluates -- with a handful of them the actual residue may be 0 (tools/fuzz_parity.py
@@ -1464,7 +1494,10 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
       const bool resolved = !ep_on[c] || (!snapshot && !drifted && !path_dependent &&
                             (D >= kResolvedRatio * eta || deep_floor));
       const unsigned long long bad = ballot64(!resolved);
-      if (bad) first_bad = c * kWave + __builtin_ctzll(bad);
+      if (bad) {
+        const int e1 = __builtin_ctzll(bad) * NCH + c;
+        first_bad = e1 < first_bad ? e1 : first_bad;
+      }
     }
     if (lane == 0) s_misc[3] = E - first_bad;
   }
@@ -1473,7 +1506,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     for (int c = 0; c < NCH; c++) {
       if (ep_on[c]) {
         if (lam_e[c] != lam_e[c]) my_flags |= COLATE_FLAG_NAN;
-        p.out_rates[(size_t)rep * E + c * kWave + lane] = lam_e[c];
+        p.out_rates[(size_t)rep * E + ep_of(c)] = lam_e[c];
       }
     }
   }

@@ -69,10 +69,11 @@ int main(int argc, char** argv) {
 #endif
   const char* names[16] = {"P2 start (gathers)", "P2 bin math", "P2 seg-reduce+store", "barrier 2", "P3 N,D + store", "P4 divide+masks", "P4 wait at barrier 3", "loop top/stop",
                            "P1 cs scan", "P1 exp/div/write", "P3 tail loads", "P3 suffix scan (A)", "P3 affine scan (B)", "P4 N,D LDS loads+adds", "-", "-"};
-  for (int w = 0; w < 2; w++) {
+  for (int w = 0; w < 4; w++) {
     unsigned long long tot = 0;
     for (int i = 0; i < 16; i++) tot += dbg[(size_t)w * 16 + i];
-    printf("replicate 0 role %d leader: total %llu cycles, %.0f per iteration\n", w, tot, (double)tot / (it[0] + 1));
+    if (!tot) continue;
+    printf("replicate 0 wave %d (role %d, bin group %d): total %llu cycles, %.0f per iteration\n", w, w & 1, w >> 1, tot, (double)tot / (it[0] + 1));
     for (int i = 0; i < 16; i++)
       if (dbg[(size_t)w * 16 + i])
         printf("   %-20s %8.0f cyc/iter  %5.1f%%\n", names[i], (double)dbg[(size_t)w * 16 + i] / (it[0] + 1), 100.0 * dbg[(size_t)w * 16 + i] / tot);

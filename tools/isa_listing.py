@@ -69,7 +69,9 @@ def cls(op, args):
     return "other"
 
 
-kinds = {"C0, C1, C0": "role A (shared) leader", "C1, C1, C0": "role B (not shared) leader",
+kinds = {"C0, C2, C0": "role A (shared), split: even epochs (wave 0)", "C1, C2, C0": "role B (not shared), split: even epochs (wave 1)",
+         "C0, C3, C1": "role A, split: odd epochs, keeps the verdict history (wave 2)", "C1, C3, C0": "role B, split: odd epochs (wave 3)",
+         "C0, C1, C0": "role A (shared) leader", "C1, C1, C0": "role B (not shared) leader",
          "C0, C0, C1": "role A second bin group, keeps the verdict history", "C1, C0, C0": "role B second bin group",
          "C0, C1, C1": "role A leader that also keeps the verdict history (one bin group only)", "C0, C0, C0": "role A further bin groups"}
 print(f"# Steady-state EM loops of {pat} (gfx950), built as the Makefile builds em_kernels_ilp.hip")
@@ -86,7 +88,7 @@ for k, (a, op, args, line) in enumerate(ins):
     k0 = index[t]
     if sum(1 for x in ins[k0:k] if x[1] == "s_barrier") != 3:
         continue
-    tags = {m.group(1) for x in ins[k0:k + 1] if x[3] for m in [re.search(r"COLATE_BOTH\(([^)]*)\)", impl_lines[x[3] - 1])] if m}
+    tags = {m.group(1) for x in ins[k0:k + 1] if x[3] for m in [re.search(r"COLATE_BOTH(?:_B)?\(([^)]*)\)", impl_lines[x[3] - 1])] if m}
     if len(tags) == 1:
         found[tags.pop()].append((k - k0, k0, k))
 loops = []
