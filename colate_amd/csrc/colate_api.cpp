@@ -3,6 +3,7 @@
 // buffers for the host-pointer variants, kernel launch.  No CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -52,6 +53,36 @@ static int check_sizes(int B, int E, int A) {
     return fail(COLATE_ELIMIT, "E=%d / A=%d above compiled limits (%d / %d)", E, A,
                 COLATE_EM_MAX_E, COLATE_EM_MAX_A);
   return COLATE_OK;
+}
+
+// ---- profiler ranges (roctx), bound on first use
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+};
+const Roctx& roctx() {
+  static const Roctx r = [] {
+    Roctx x;
+    if (!std::getenv("COLATE_ROCTX")) return x;  // (opt-in: COLATE_ROCTX=1 under `rocprofv3 --marker-trace`; otherwise no profiler library is loaded)
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) {
+        x.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        x.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (x.push && x.pop) break;
+        x.push = nullptr, x.pop = nullptr;
+      }
+    }
+    return x;
+  }();
+  return r;
+}
+}  // namespace
+ProfRange::ProfRange(const char* name) {
+  if (roctx().push) roctx().push(name);
+}
+ProfRange::~ProfRange() {
+  if (roctx().pop) roctx().pop();
 }
 
 static std::atomic<int> g_device_touched{0};
@@ -347,13 +378,51 @@ static int em_batch_host(bool per_row, int B, int E, int A, const double* age_gr
     if (int rc = check_grids(E, A, age_grid, epochs + (size_t)b * E)) return rc;
   if (int rc = ensure_device()) return rc;
   if (B == 0) return COLATE_OK;
+  ProfRange range("colate_em_batch: H2D + EM kernel + D2H");
   const size_t nBA = (size_t)B * A, nBE = (size_t)B * E, nEp = per_row ? nBE : (size_t)E;
   Stage st;
   const int i_grid = st.in(age_grid, A), i_sh = st.in(cnt_shared, nBA), i_ns = st.in(cnt_notshared, nBA);
   const int i_ep = st.in(epochs, nEp), i_init = st.in(init_rates, nEp);
   const int o_rates = st.out(out_rates, nBE), o_ll = st.out(out_loglik, B), o_iters = st.out(out_iters, B),
             o_flags = st.out(out_flags, B);
+  // COLATE_LL_TRACE=<file>: the log-likelihood of every iteration (the reference's commented-out trace, coal.cpp:3659,
+  // 3674, 3817, 3821), "replicate iteration loglik" per line.  Diagnostic: the run then takes the general loop with the
+  // log-likelihood evaluated in every iteration (same rates, slower); at most the first kTraceCap iterations are kept.
+  const char* trace_path = std::getenv("COLATE_LL_TRACE");
+  constexpr int kTraceCap = 8192;
+  const int cap = trace_path ? (max_iter < kTraceCap ? max_iter : kTraceCap) : 0;
+  std::vector<double> trace;
+  int o_trace = -1;
+  if (cap > 0) {
+    trace.resize((size_t)B * cap);
+    o_trace = st.out(trace.data(), trace.size());
+  }
   if (int rc = st.commit()) return rc;
+  if (cap > 0) {
+    HIP_TRY(hipMemsetAsync(st.dev<double>(o_trace), 0xff, trace.size() * sizeof(double), st.stream()));  // NaN = "not reached"
+    if (int rc = check_sizes(B, E, A)) return rc;
+    ColateEmArgs a{};
+    a.B = B, a.E = E, a.A = A, a.mode = 0;
+    a.age_grid = st.dev<double>(i_grid), a.cnt_sh = st.dev<double>(i_sh), a.cnt_ns = st.dev<double>(i_ns);
+    a.epochs = st.dev<double>(i_ep), a.epochs_stride = per_row ? E : 0;
+    a.rates_in = st.dev<double>(i_init), a.rates_stride = per_row ? E : 0;
+    a.max_iter = max_iter, a.min_iter = min_iter, a.rel_tol = rel_tol, a.rate_floor = rate_floor;
+    a.out_rates = st.dev<double>(o_rates), a.out_iters = st.dev<int>(o_iters), a.out_ll = st.dev<double>(o_ll);
+    a.out_flags = st.dev<int>(o_flags);
+    a.ll_trace = st.dev<double>(o_trace), a.ll_trace_cap = cap;
+    if (max_iter < 1) return fail(COLATE_EINVAL, "max_iter must be >= 1");
+    if (int rc = launch(a, st.stream())) return rc;
+    if (int rc = st.finish()) return rc;
+    FILE* f = std::fopen(trace_path, "w");
+    if (!f) return fail(COLATE_EIO, "cannot write %s", trace_path);
+    for (int b = 0; b < B; b++)
+      for (int it = 0; it < cap; it++) {
+        const double v = trace[(size_t)b * cap + it];
+        if (v == v) std::fprintf(f, "%d %d %.17g\n", b, it, v);
+      }
+    std::fclose(f);
+    return COLATE_OK;
+  }
   if (int rc = colate_em_batch_device(B, E, A, st.dev<double>(i_grid), st.dev<double>(i_sh), st.dev<double>(i_ns),
                                       st.dev<double>(i_ep), per_row, st.dev<double>(i_init), per_row, max_iter,
                                       min_iter, rel_tol, rate_floor, st.dev<double>(o_rates), st.dev<int>(o_iters),
@@ -415,6 +484,7 @@ int colate_bootstrap_em_batch(int B, int nb, int E, int A, const double* age_gri
   if (int rc = check_grids(E, A, age_grid, epochs)) return rc;
   if (int rc = ensure_device()) return rc;
   if (B == 0) return COLATE_OK;
+  ProfRange range("colate_bootstrap_em_batch: H2D + bootstrap kernel + EM kernel + D2H");
   const size_t nT = (size_t)nb * A, nBA = (size_t)B * A, nBE = (size_t)B * E;
   Stage st;
   const int i_grid = st.in(age_grid, A), i_w = st.in(weights, (size_t)B * nb);

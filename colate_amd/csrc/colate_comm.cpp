@@ -153,10 +153,14 @@ int run_and_gather(Comm* c, int B, int E, double* out_rates, int* out_iters, dou
   if (const char* inj = getenv("COLATE_TEST_FAIL_RANK")) {  // failure injection for the tests of exactly this path
     if (atoi(inj) == c->rank) local_rc = fail(COLATE_EHIP, "injected failure on rank %d (COLATE_TEST_FAIL_RANK)", c->rank);
   }
-  if (!local_rc && hi > lo) local_rc = local(hi - lo, lo, d_rates, d_ll, d_iters, d_flags, c->stream);
+  if (!local_rc && hi > lo) {
+    colate::ProfRange range("colate shard: bootstrap + EM on this rank's replicates");
+    local_rc = local(hi - lo, lo, d_rates, d_ll, d_iters, d_flags, c->stream);
+  }
   std::string local_msg = local_rc ? colate_last_error() : "";
   if (local_rc) (void)hipMemcpyAsync(c->d_send + per_rank - 8, &local_rc, sizeof(int), hipMemcpyHostToDevice, c->stream);
   // the ONE collective of the path: per_rank bytes from every rank to every rank
+  colate::ProfRange gather_range("colate all-gather of the packed results (RCCL)");
   NCCL_TRY(rccl().AllGather(c->d_send, c->d_recv, per_rank, ncclChar, c->nccl, c->stream));
   if (c->h_recv && c->hcap >= per_rank * c->nranks)
     HIP_TRY(hipMemcpyAsync(c->h_recv, c->d_recv, per_rank * c->nranks, hipMemcpyDeviceToHost, c->stream));

@@ -12,4 +12,12 @@ int check_grids(int E, int A, const double* age_grid, const double* epochs);
 // that has done so must not fork() children that use the GPU: `Colate --ranks N` (run_ranked, mut_driver.cpp) refuses
 // when it is set (colate_device_touched, include/colate_amd.h).
 void mark_device_touched();
+// A named range for profilers (rocprofv3 --marker-trace): roctxRangePush / roctxRangePop, bound lazily with dlopen so that the
+// library has no link-time dependency on a profiler; a no-op where librocprofiler-sdk-roctx / libroctx64 is not present.
+struct ProfRange {
+  explicit ProfRange(const char* name);
+  ~ProfRange();
+  ProfRange(const ProfRange&) = delete;
+  ProfRange& operator=(const ProfRange&) = delete;
+};
 }  // namespace colate

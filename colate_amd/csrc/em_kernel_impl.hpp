@@ -216,17 +216,17 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput) {
 #else
   (void)erows;
   if (mode != 0) return 0;
-  // measured on MI355X, kernel ms for pads 0..7, final loop code of round 2 (gpurun_out/r02zz/padsweep.txt ->
-  // profiles/r02_placement.txt).  The pad shifts everything behind it, the loops compiled per kind of wave included.
+  // measured on MI355X, kernel ms for pads 0..7, loop code of round 3 (gpurun_out/r03j/padsweep.txt -> profiles/r03_placement.txt).
+  // The pad shifts everything behind it, the loops compiled per kind of wave included.
 #ifdef COLATE_EM_ILP_BUILD
   (void)tput;
-  // latency variant, max-ilp build: E=23 B=100 1.019 1.031 1.023 1.030 0.998 1.021 1.010 1.011 (B=400: 1.224 1.245 1.236 1.235 1.208 1.230 1.219 1.235);
-  // E=122 B=100 1.490 1.504 1.507 1.503 1.521 1.491 1.505 1.481
-  return nch == 1 ? 4 : 7;
+  // latency variant, max-ilp build: E=23 B=100 1.015 1.036 1.017 1.033 1.028 1.031 1.027 1.028;
+  // E=122 B=100 1.378 1.355 1.370 1.355 1.356 1.363 1.364 1.375
+  return nch == 1 ? 0 : 3;
 #else
   (void)nch;
   if (!tput) return 6;  // latency variant, default build (not picked by colate_em_variant any more; COLATE_EM_VARIANT=latency)
-  return 4;             // throughput variant: E=23 B=4096 6.680 6.622 6.657 6.640 6.617 6.677 6.648 6.643
+  return 0;             // throughput variant: E=23 B=4096 6.605 6.625 6.657 6.637 6.694 6.678 6.623 6.681
 #endif
 #endif
 }
@@ -251,7 +251,10 @@ constexpr int em_loop_pad2(int mode, int nch, bool tput) {
 // slots and fewer registers per replicate, so three times as many replicates are resident per CU and fill
 // the issue slots that a lone workgroup leaves empty at its barriers.
 template <int MODE, int NCH, int EROWS, bool TPUT>
-__global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_kernel(ColateEmArgs p) {
+// (second launch bound = waves per SIMD the register allocation must leave room for: three at up to 64 epochs -- two 6-wave
+// workgroups of the latency variant, six 2-wave ones of the throughput variant per CU: B = 400 ran 2.01 instead of 1.21 ms
+// when the tail model's refresh block took the kernel to 182 registers -- two at up to 128, one beyond)
+__global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, (NCH == 1) ? 3 : (NCH == 2 ? 2 : 1)) void em_kernel(ColateEmArgs p) {
   extern __shared__ double lds[];
   const int E = p.E, A = p.A;
   constexpr int EPAD = NCH * kWave;
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     constexpr int kOwn = (kLeader == 3) ? 1 : 0;
     static_assert(!kSplit || NCH == 2, "the split is for two epochs per lane");
     auto own = [&](int c) { return !kSplit || c == kOwn; };
-    const bool need_ll = kNeedLL < 0 ? ((MODE == 1) || (iter >= p.min_iter) || (iter == max_iter - 1)) : (kNeedLL != 0);
+    const bool need_ll = kNeedLL < 0 ? ((MODE == 1) || (iter >= p.min_iter) || (iter == max_iter - 1) || p.ll_trace != nullptr) : (kNeedLL != 0);
     // ============================================================ P1: epoch values (ROLE leaders)
     double q_e[NCH], p_e[NCH], beta_e[NCH], S_e[NCH], omS_e[NCH], cs_e[NCH];
 #pragma unroll
@@ -1178,6 +1181,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
     if (need_ll) {
       COLATE_COLD();
       ll = ((s_ll[0] + s_ll[1]) + (s_ll[2] + s_ll[3])) + ((s_ll[4] + s_ll[5]) + (s_ll[6] + s_ll[7]));  // retired waves: 0
+      if (kNeedLL < 0 && p.ll_trace && tid == 0 && iter < p.ll_trace_cap) p.ll_trace[(size_t)rep * p.ll_trace_cap + iter] = ll;
     }
     if (MODE == 1) {
       if (wave == 0) {
@@ -1276,7 +1280,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A) void em_ker
   // The waves of a workgroup run different loops but the same sequence of barriers.  The general loop below is what is
   // left for MODE 1 and for the rare wave whose epochs need more than two tail slots.
   bool stopped = false;
-  if (MODE == 0) {
+  if (MODE == 0 && p.ll_trace == nullptr) {  // (the per-iteration log-likelihood trace runs everything in the general loop)
     int n_steady = p.min_iter < max_iter - 1 ? p.min_iter : max_iter - 1;
     if (n_steady < 0) n_steady = 0;
     using C0 = std::integral_constant<int, 0>;

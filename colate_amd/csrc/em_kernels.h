@@ -33,6 +33,8 @@ struct ColateEmArgs {
   int* out_flags;     // [B]
   double* out_num;    // [B][E] (mode 1)
   double* out_den;    // [B][E] (mode 1)
+  double* ll_trace;   // [B][ll_trace_cap] or NULL: the log-likelihood of every iteration (diagnostic; general loop only)
+  int ll_trace_cap;
 };
 
 size_t colate_em_lds_bytes(int E, int A);

@@ -21,6 +21,8 @@ int fail(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
+ProfRange::ProfRange(const char*) {}
+ProfRange::~ProfRange() {}
 }  // namespace colate
 
 static int nodev() { return colate::fail(COLATE_ENODEVICE, "host sanitizer build: no device code linked"); }

@@ -508,3 +508,29 @@ def test_device_bootstrap_bit_identical_to_host(ca):
                        torch.full((E,), ca.DEFAULT_INIT_RATE, **f64), out, it, ll, fl, max_iter=60)
     r0, it0, _, _ = ca.em_batch(grid, h_sh, h_ns, ep, max_iter=60)
     assert np.array_equal(out.cpu().numpy(), r0)
+
+
+def test_loglik_trace_and_profiler_ranges(ca, tmp_path, monkeypatch):
+    """COLATE_LL_TRACE=<file>: the log-likelihood of every iteration (the reference's commented-out trace, coal.cpp:3659,
+    3817): same rates, iterations and final log-likelihood as the untraced run, one line per executed E-step, and the
+    sequence increases like an EM's.  COLATE_ROCTX=1 (roctx ranges around the host-pointer calls) must not change anything."""
+    from colate_amd import workloads
+
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins("3,7,0.2")
+    csh, cns = workloads.bootstrap_tables(grid, 3, nb=9, scale=1.0)
+    kw = dict(max_iter=300, min_iter=100)
+    r0, it0, ll0, fl0 = ca.em_batch(grid, csh, cns, ep, **kw)
+    path = tmp_path / "ll.txt"
+    monkeypatch.setenv("COLATE_LL_TRACE", str(path))
+    monkeypatch.setenv("COLATE_ROCTX", "1")
+    r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep, **kw)
+    monkeypatch.delenv("COLATE_LL_TRACE")
+    assert np.array_equal(r0, r1) and np.array_equal(it0, it1) and np.array_equal(ll0, ll1) and np.array_equal(fl0, fl1)
+    rows = np.loadtxt(path)
+    for b in range(3):
+        tr = rows[rows[:, 0] == b]
+        n_esteps = min(int(it0[b]) + 1, 300)
+        assert len(tr) == n_esteps and (tr[:, 1] == np.arange(n_esteps)).all()
+        assert tr[-1, 2] == ll0[b]
+        assert (np.diff(tr[:, 2]) >= -1e-9 * np.abs(tr[1:, 2])).all()  # the EM's log-likelihood does not decrease
