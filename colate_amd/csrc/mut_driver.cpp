@@ -16,6 +16,7 @@
 #include <signal.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <cmath>
@@ -322,21 +323,31 @@ bool read_mut_file(const std::string& filename, std::vector<MutRow>& rows) {
 // so the order of the draws is part of the result -- but nothing of the parsing depends on it.
 class MutPrefetcher {
  public:
-  explicit MutPrefetcher(std::vector<std::string> files) : files_(std::move(files)) {
-    worker_ = std::thread([this] {
-      for (const std::string& f : files_) {
-        std::vector<MutRow> rows;
-        const double t0 = StageTimes::now();
-        read_mut_file(f, rows);
-        const double dt = StageTimes::now() - t0;
-        std::unique_lock<std::mutex> lk(m_);
-        parse_seconds_ += dt;
-        cv_.wait(lk, [this] { return q_.size() < 2 || stop_; });
-        if (stop_) return;
-        q_.push_back(std::move(rows));
-        cv_.notify_all();
-      }
-    });
+  explicit MutPrefetcher(std::vector<std::string> files) : files_(std::move(files)), slots_(files_.size()) {
+    const unsigned hc = std::thread::hardware_concurrency();
+    const int nthreads = (hc >= 6 && files_.size() > 1) ? 2 : 1;
+    for (int t = 0; t < nthreads; t++)
+      workers_.emplace_back([this] {
+        for (;;) {
+          size_t i;
+          {
+            std::unique_lock<std::mutex> lk(m_);
+            // at most kAhead files parsed beyond the one the fill is at (memory: ~56 MB per million rows)
+            cv_.wait(lk, [this] { return stop_ || next_ >= files_.size() || next_ < consumed_ + kAhead; });
+            if (stop_ || next_ >= files_.size()) return;
+            i = next_++;
+          }
+          std::vector<MutRow> rows;
+          const double t0 = StageTimes::now();
+          read_mut_file(files_[i], rows);
+          const double dt = StageTimes::now() - t0;
+          std::lock_guard<std::mutex> lk(m_);
+          parse_seconds_ += dt;
+          slots_[i].rows = std::move(rows);
+          slots_[i].ready = true;
+          cv_.notify_all();
+        }
+      });
   }
   ~MutPrefetcher() {
     {
@@ -344,25 +355,33 @@ class MutPrefetcher {
       stop_ = true;
     }
     cv_.notify_all();
-    if (worker_.joinable()) worker_.join();
+    for (std::thread& t : workers_)
+      if (t.joinable()) t.join();
   }
   void next(std::vector<MutRow>& rows) {  // the next file's rows, in the order given
     const double t0 = StageTimes::now();
     std::unique_lock<std::mutex> lk(m_);
-    cv_.wait(lk, [this] { return !q_.empty(); });
-    rows = std::move(q_.front());
-    q_.pop_front();
+    const size_t i = consumed_;
+    cv_.wait(lk, [&] { return slots_[i].ready; });
+    rows = std::move(slots_[i].rows);
+    consumed_++;
     g_times.wait_for_parser += StageTimes::now() - t0;
     g_times.parse_mut = parse_seconds_;
     cv_.notify_all();
   }
 
  private:
+  static constexpr size_t kAhead = 3;
+  struct Slot {
+    std::vector<MutRow> rows;
+    bool ready = false;
+  };
   std::vector<std::string> files_;
-  std::thread worker_;
+  std::vector<Slot> slots_;
+  std::vector<std::thread> workers_;
   std::mutex m_;
   std::condition_variable cv_;
-  std::deque<std::vector<MutRow>> q_;
+  size_t next_ = 0, consumed_ = 0;
   double parse_seconds_ = 0;
   bool stop_ = false;
 };
@@ -425,13 +444,216 @@ inline int age_bin_index(double x, double C) {  // coal.cpp:2265, 2284
   return std::max(0, (int)v + 1);
 }
 
+// ---- sampling of the mutation ages, off the main thread ---------------------------------------------------------------
+// Every used SNP spreads its weight over 100 ages drawn uniformly between age_begin and age_end (coal.cpp:2260-2295), each
+// draw one std::uniform_real_distribution<double>(0,1) call on the run's single std::mt19937: the ORDER of the draws is part
+// of the result, their evaluation is not.  The main thread therefore walks the SNPs (filters, stream merges: sequential by
+// nature), draws the uniforms in the reference's order into a buffer per genome block, and hands the block to a worker, which
+// does the log / round / accumulate per draw (two thirds of the time of the whole table fill).  A genome block's tables are
+// touched by one job only and the SNPs of a job are taken in order, so every table cell sums the same terms in the same
+// order as the reference: bit-identical.  One case breaks the fixed "100 draws per SNP": the reference REdraws a sample whose
+// age bin lies beyond the grid (coal.cpp:2286-2287, ages above 9e6 generations); a worker that meets one raises `redo` and
+// the whole fill is repeated on the sequential path.
+struct UsedSnp {
+  double age_begin, age_end, w_sh, w_ns;
+  bool emp;  // age_begin <= sample age: the F path (coal.cpp:2245-2275), not-shared weight only, no redraws
+};
+struct SampleJob {
+  std::vector<UsedSnp> snps;
+  std::vector<double> u;  // 100 uniforms per SNP, in draw order
+  double *sh = nullptr, *ns = nullptr;  // the block's two tables (buffers of tab.sh[blk], tab.ns[blk]: stable while blocks are added)
+};
+class SamplePool {
+ public:
+  SamplePool(int nthreads, double C, int A, double age) : C_(C), A_(A), age_(age) {
+    for (int i = 0; i < nthreads; i++) workers_.emplace_back([this] { run(); });
+  }
+  ~SamplePool() { finish(); }
+  void submit(SampleJob&& j) {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_room_.wait(lk, [this] { return q_.size() < 2 * workers_.size() + 2; });  // bounds the uniforms held in memory
+    q_.push_back(std::move(j));
+    cv_work_.notify_one();
+  }
+  void finish() {  // waits for all jobs
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      done_ = true;
+    }
+    cv_work_.notify_all();
+    for (std::thread& t : workers_)
+      if (t.joinable()) t.join();
+    workers_.clear();
+  }
+  bool redo() const { return redo_.load(); }
+
+ private:
+  void run() {
+    for (;;) {
+      SampleJob j;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_work_.wait(lk, [this] { return !q_.empty() || done_; });
+        if (q_.empty()) return;
+        j = std::move(q_.front());
+        q_.pop_front();
+        cv_room_.notify_one();
+      }
+      if (redo_.load()) continue;
+      double *sh = j.sh, *ns = j.ns;
+      const double* u = j.u.data();
+      for (const UsedSnp& s : j.snps) {
+        const double span = s.age_end - s.age_begin;
+        if (s.emp) {
+          for (int k = 0; k < 100; k++) {
+            double sampled_age = u[k] * span + s.age_begin;
+            if (sampled_age < age_) sampled_age = age_;
+            const int bin = age_bin_index(sampled_age, C_);
+            if (bin < A_) ns[bin] += s.w_ns;
+          }
+        } else {
+          for (int k = 0; k < 100; k++) {
+            const double sampled_age = u[k] * span + s.age_begin;
+            const int bin = age_bin_index(sampled_age, C_);
+            if (sampled_age < age_ || bin >= A_) {  // the reference would draw again: the stream no longer lines up
+              redo_.store(true);
+              break;
+            }
+            sh[bin] += s.w_sh;
+            ns[bin] += s.w_ns;
+          }
+          if (redo_.load()) break;
+        }
+        u += 100;
+      }
+    }
+  }
+  const double C_;
+  const int A_;
+  const double age_;
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_work_, cv_room_;
+  std::deque<SampleJob> q_;
+  bool done_ = false;
+  std::atomic<bool> redo_{false};
+};
+// std::uniform_real_distribution<double>(0, 1) on std::mt19937 is std::generate_canonical<double, 53>: two 32-bit draws,
+// (r1 + r2 * 2^32) / 2^64 in double, capped below 1 (libstdc++ bits/random.tcc).  The same arithmetic spelled out costs a
+// third (the library version goes through long double); it is used only after a self-check against the library's own
+// distribution on this machine's libstdc++ (the sequence is part of the result), else the library call is.
+inline double canonical_fast(std::mt19937& g) {
+  const double r1 = (double)g();
+  const double r2 = (double)g();
+  double ret = (r1 + r2 * 4294967296.0) * 0x1p-64;
+  if (ret >= 1.0) ret = std::nextafter(1.0, 0.0);
+  return ret;
+}
+inline bool canonical_fast_ok() {
+  static const bool ok = [] {
+    for (unsigned seed : {1u, 12345u, 4294967295u}) {
+      std::mt19937 a(seed), b(seed);
+      std::uniform_real_distribution<double> d(0, 1);
+      for (int i = 0; i < 4096; i++)
+        if (d(a) != canonical_fast(b)) return false;
+      if (a != b) return false;
+    }
+    return true;
+  }();
+  return ok;
+}
+
+// The uniforms themselves, on a thread of their own: the stream does not depend on the data, only HOW MANY of its values the
+// fill takes does.  The thread runs ahead on a copy of the run's generator, filling chunks of kChunk doubles, and keeps the
+// generator state at the start of every chunk; when the fill is over, the run's generator is set to the state at the start of
+// the last chunk touched and advanced by the few draws taken from it -- exactly where the sequential code would have left it.
+class UniformStream {
+ public:
+  static constexpr size_t kChunk = 1u << 18;  // doubles per chunk (2 MB)
+  UniformStream(const std::mt19937& start, bool fast) : gen_(start), fast_(fast) {
+    worker_ = std::thread([this] { run(); });
+  }
+  ~UniformStream() { stop(); }
+  void take(double* out, size_t n) {  // the next n uniforms of the stream
+    while (n) {
+      if (!cur_ || pos_ == kChunk) next_chunk();
+      const size_t k = std::min(n, kChunk - pos_);
+      std::memcpy(out, cur_->u.data() + pos_, k * sizeof(double));
+      out += k, n -= k, pos_ += k;
+    }
+  }
+  // the generator as the sequential code would hold it now (after every uniform handed out so far)
+  std::mt19937 state_after_taken() {
+    stop();
+    if (!cur_) return first_;
+    std::mt19937 g = cur_->at_start;
+    g.discard(2 * (unsigned long long)pos_);  // two 32-bit draws per uniform (generate_canonical<double, 53>)
+    return g;
+  }
+
+ private:
+  struct Chunk {
+    std::mt19937 at_start;
+    std::vector<double> u;
+  };
+  void run() {
+    std::uniform_real_distribution<double> d(0, 1);
+    for (;;) {
+      std::unique_ptr<Chunk> c(new Chunk);
+      c->at_start = gen_;
+      c->u.resize(kChunk);
+      if (fast_)
+        for (size_t i = 0; i < kChunk; i++) c->u[i] = canonical_fast(gen_);
+      else
+        for (size_t i = 0; i < kChunk; i++) c->u[i] = d(gen_);
+      std::unique_lock<std::mutex> lk(m_);
+      cv_room_.wait(lk, [this] { return ready_.size() < 8 || stop_; });
+      if (stop_) return;
+      ready_.push_back(std::move(c));
+      cv_ready_.notify_one();
+    }
+  }
+  void next_chunk() {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_ready_.wait(lk, [this] { return !ready_.empty(); });
+    cur_ = std::move(ready_.front());
+    ready_.pop_front();
+    pos_ = 0;
+    cv_room_.notify_one();
+  }
+  void stop() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_room_.notify_all();
+    if (worker_.joinable()) worker_.join();
+  }
+  std::mt19937 gen_;
+  const std::mt19937 first_ = gen_;
+  const bool fast_;
+  std::thread worker_;
+  std::mutex m_;
+  std::condition_variable cv_ready_, cv_room_;
+  std::deque<std::unique_ptr<Chunk>> ready_;
+  std::unique_ptr<Chunk> cur_;
+  size_t pos_ = 0;
+  bool stop_ = false;
+};
+
+inline int sample_threads() {
+  if (const char* e = std::getenv("COLATE_THREADS")) return std::max(0, std::atoi(e) - 1);
+  const unsigned hc = std::thread::hardware_concurrency();
+  return hc >= 4 ? (int)std::min(hc - 2, 12u) : 0;  // 0: sample on the main thread (the sequential path)
+}
+
 // coal.cpp:2071-2321.  Returns the number of blocks.
-int fill_tables_from_tmp(const std::vector<std::string>& chr_names,
-                         const std::vector<std::string>& mut_files, const std::string& target_file,
-                         const std::string& ref_file, const std::vector<std::string>& target_masks,
-                         const std::vector<std::string>& ref_masks, double C, std::mt19937& rng,
-                         int num_bases_per_block, int A, BlockTables& tab,
-                         std::map<std::string, std::vector<MutRow>>* mut_cache = nullptr) {
+int fill_tables_impl(const std::vector<std::string>& chr_names,
+                     const std::vector<std::string>& mut_files, const std::string& target_file,
+                     const std::string& ref_file, const std::vector<std::string>& target_masks,
+                     const std::vector<std::string>& ref_masks, double C, std::mt19937& rng,
+                     int num_bases_per_block, int A, BlockTables& tab,
+                     std::map<std::string, std::vector<MutRow>>* mut_cache, SamplePool* pool) {
   const double age = 0, ref_age = 0;  // forced, coal.cpp:2074-2075
   std::uniform_real_distribution<double> dist_unif(0, 1);
   const float num_samples = 100;
@@ -445,7 +667,24 @@ int fill_tables_from_tmp(const std::vector<std::string>& chr_names,
   int num_blocks = 0;
   size_t blk = 0;
   tab.add_block(A);
+  SampleJob job;  // (pool) the used SNPs of the current block and their uniforms
+  auto flush_job = [&]() {
+    if (pool && !job.snps.empty()) {
+      job.sh = tab.sh[blk].data();
+      job.ns = tab.ns[blk].data();
+      pool->submit(std::move(job));
+      job = SampleJob();
+    }
+  };
+  std::unique_ptr<UniformStream> stream;  // (pool) the run's uniforms, generated ahead on their own thread
+  if (pool) stream.reset(new UniformStream(rng, canonical_fast_ok()));
+  auto draw100 = [&]() {  // the SNP's 100 uniforms, in the reference's draw order
+    const size_t at = job.u.size();
+    job.u.resize(at + 100);
+    stream->take(job.u.data() + at, 100);
+  };
   auto advance_block = [&]() {
+    flush_job();
     blk++;
     num_blocks++;
     if (blk >= tab.sh.size()) tab.add_block(A);
@@ -544,13 +783,22 @@ int fill_tables_from_tmp(const std::vector<std::string>& chr_names,
           tab.sh_emp[blk][bin2] += f_DAF_target * DAF_ref / ((double)N_ref);
           tab.ns_emp[blk][bin2] += f_AAF_target * DAF_ref / ((double)N_ref);
         }
-        for (int j = 0; j < num_samples; j++) {
-          double sampled_age = dist_unif(rng) * (m.age_end - age_begin) + age_begin;
-          if (sampled_age < age) sampled_age = age;
-          const int bin = age_bin_index(sampled_age, C);
-          if (bin < A) ns[bin] += f_AAF_target * DAF_ref / ((double)N_ref * num_samples);
+        if (pool) {  // the draws now, in the reference's order; their evaluation on a worker
+          job.snps.push_back(UsedSnp{age_begin, (double)m.age_end, 0.0, f_AAF_target * DAF_ref / ((double)N_ref * num_samples), true});
+          draw100();
+        } else {
+          for (int j = 0; j < num_samples; j++) {
+            double sampled_age = dist_unif(rng) * (m.age_end - age_begin) + age_begin;
+            if (sampled_age < age) sampled_age = age;
+            const int bin = age_bin_index(sampled_age, C);
+            if (bin < A) ns[bin] += f_AAF_target * DAF_ref / ((double)N_ref * num_samples);
+          }
         }
-      } else {  // coal.cpp:2277-2297
+      } else if (pool) {  // coal.cpp:2277-2297
+        job.snps.push_back(UsedSnp{age_begin, (double)m.age_end, f_DAF_target * DAF_ref / ((double)N_ref * num_samples),
+                                   f_AAF_target * DAF_ref / ((double)N_ref * num_samples), false});
+        draw100();
+      } else {
         int j = 0;
         while (j < num_samples) {
           const double sampled_age = dist_unif(rng) * (m.age_end - age_begin) + age_begin;
@@ -564,17 +812,49 @@ int fill_tables_from_tmp(const std::vector<std::string>& chr_names,
           }
         }
       }
+      if (pool && pool->redo()) break;  // (a redraw was needed somewhere: this pass is void)
     }
     advance_block();  // chromosome end, coal.cpp:2306-2310
     g_times.table_fill += StageTimes::now() - t_fill0;
   }
   if (tgt.fp) std::fclose(tgt.fp);
   if (ref.fp) std::fclose(ref.fp);
+  if (pool) {
+    pool->finish();  // (before the tables are trimmed)
+    rng = stream->state_after_taken();
+  }
   tab.sh.resize(num_blocks);
   tab.ns.resize(num_blocks);
   tab.sh_emp.resize(num_blocks);
   tab.ns_emp.resize(num_blocks);
   return num_blocks;
+}
+
+// coal.cpp:2071-2321 with the sampling on worker threads where the machine has them (COLATE_THREADS=n caps the threads of
+// this process, 1 = everything on the calling thread).  Returns the number of blocks.
+int fill_tables_from_tmp(const std::vector<std::string>& chr_names,
+                         const std::vector<std::string>& mut_files, const std::string& target_file,
+                         const std::string& ref_file, const std::vector<std::string>& target_masks,
+                         const std::vector<std::string>& ref_masks, double C, std::mt19937& rng,
+                         int num_bases_per_block, int A, BlockTables& tab,
+                         std::map<std::string, std::vector<MutRow>>* mut_cache = nullptr) {
+  const int nt = sample_threads();
+  if (nt > 0) {
+    const std::mt19937 rng0 = rng;
+    BlockTables t2;
+    SamplePool pool(nt, C, A, /*age=*/0.0);
+    const int nb = fill_tables_impl(chr_names, mut_files, target_file, ref_file, target_masks, ref_masks, C, rng,
+                                    num_bases_per_block, A, t2, mut_cache, &pool);
+    pool.finish();
+    if (!pool.redo()) {
+      tab = std::move(t2);
+      return nb;
+    }
+    rng = rng0;  // a sample beyond the age grid had to be redrawn: once more, on the sequential path
+    if (g_times.on) std::cerr << "Timing: a sample beyond the age grid was redrawn; the table fill is repeated sequentially" << std::endl;
+  }
+  return fill_tables_impl(chr_names, mut_files, target_file, ref_file, target_masks, ref_masks, C, rng, num_bases_per_block, A,
+                          tab, mut_cache, nullptr);
 }
 
 // OUT.colate_mat (coal.cpp:3471-3499): 185 grid values, then per replicate 185 shared

@@ -402,3 +402,51 @@ def test_ranks_refused_once_the_process_has_used_the_device(ca, tmp_path):
     )
     r = subprocess.run([os.sys.executable, "-c", code, str(tmp_path / "o")], cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "must run before this process first uses a GPU" in r.stderr, (r.returncode, r.stderr)
+
+
+def _counts(tmp_path, threads, extra=()):
+    env = dict(os.environ, COLATE_THREADS=str(threads), COLATE_TIMING="1")
+    out = f"c{threads}"
+    r = subprocess.run([CLI, "--mode", "mut", "--mut", "P", "--target_tmp", "T.colate.in", "--reference_tmp", "R.colate.in", "--chr",
+                        "chr.txt", "--bins", "3,7,0.2", "--seed", "11", "--num_bootstraps", "7", "--counts_only", "--counts_out",
+                        out + ".counts", "-o", out] + list(extra), cwd=str(tmp_path), capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert "Timing: parse_mut" in r.stderr
+    _counts.redone = "repeated sequentially" in r.stderr
+    return (tmp_path / (out + ".counts")).read_text()
+
+
+def test_threaded_table_fill_is_bit_identical_to_sequential(tmp_path):
+    """The reader threads, the uniform-stream thread and the sampling workers (mut_driver.cpp) leave the count tables -- and
+    the std::mt19937 state the bootstrap weights are drawn from afterwards -- exactly as the sequential code does."""
+    import synth_files
+
+    synth_files.write_inputs(str(tmp_path), chroms=("1", "2", "3"), snps_per_chr=4000, seed=3, gz=True)
+    threaded = _counts(tmp_path, 8)
+    assert not _counts.redone
+    assert threaded == _counts(tmp_path, 1)
+
+
+def test_threaded_table_fill_redoes_sequentially_when_a_sample_is_redrawn(tmp_path):
+    """A mutation older than the age grid makes the reference draw again (coal.cpp:2286-2287), which breaks the fixed 100
+    draws per SNP the threaded fill relies on: it must notice and repeat the fill sequentially, with the same result."""
+    import gzip
+
+    import synth_files
+
+    synth_files.write_inputs(str(tmp_path), chroms=("1", "2"), snps_per_chr=2500, seed=5, gz=True)
+    p = tmp_path / "P_chr2.mut.gz"
+    lines = gzip.open(p, "rt").read().split("\n")
+    n_changed = 0
+    for i in range(1, len(lines)):
+        f = lines[i].split(";")
+        if len(f) > 10 and f[7] == "0" and f[5] == "7" and float(f[8]) > 1e4 and n_changed < 40:
+            f[8], f[9] = "5e+06", "4e+07"  # most sampled ages lie beyond the last grid point (8.9e6 generations)
+            lines[i] = ";".join(f)
+            n_changed += 1
+    assert n_changed == 40
+    with gzip.open(p, "wt") as g:
+        g.write("\n".join(lines))
+    threaded = _counts(tmp_path, 8)
+    assert _counts.redone  # (the threaded pass gave up ...)
+    assert threaded == _counts(tmp_path, 1)  # (... and the repeat is the sequential result)

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-2 profile set (GPU box): kernel traces for every shape DESIGN.md quotes, PMC passes for the two BASELINE shapes,
-# the FETCH_SIZE calibration for 8-B-per-lane reads and the bootstrap kernel.  Output under gpurun_out/prof_r02/.
+# Round-3 profile set (GPU box): kernel traces for every shape DESIGN.md quotes, PMC passes for the two BASELINE shapes,
+# the FETCH_SIZE calibration for 8-B-per-lane reads and the bootstrap kernel.  Output under gpurun_out/prof_r03/.
 #   gpurun --timeout 1100 -- 'tools/profile_all.sh'    then   tools/collect_profiles.sh
 set -euo pipefail
 R=/root/repo
 cd $R
-P=prof_r02
+P=prof_r03
 tools/profile_bench.sh $P/b100_e23 pmc
 tools/profile_bench.sh $P/b100_e122 pmc --bins 2,7.95,0.05
 tools/profile_bench.sh $P/b400_e23 nopmc --replicates 400
