@@ -448,8 +448,10 @@ def run_rank(args):
             variant = "n/a"
         nch = 1 if E <= 64 else (2 if E <= 128 else 4)
         rows = (1 if E <= 16 else (2 if E <= 32 else 4)) if nch == 1 else 4
-        kernel_name = f"em_kernel<0, {nch}, {rows}, {'true' if variant == 'throughput' else 'false'}>"
         cus = 256 if dry else torch.cuda.get_device_properties(dev).multi_processor_count
+        # (the build without the three-waves-per-SIMD register cap runs where every workgroup has a CU to itself)
+        wpe = ", 2" if (variant == "latency-ilp" and nch == 1 and n_local <= cus) else ", 0"
+        kernel_name = f"em_kernel<0, {nch}, {rows}, {'true' if variant == 'throughput' else 'false'}{wpe}>"
         achieved = esteps * bytes_per_rep_iter / (kern_ms * 1e-3) / 1e9
         crit_iters = int(iters.max()) + 1  # the launch lasts as long as its slowest replicate (B <= #CUs: all run at once)
         waves = -(-n_local // cus)

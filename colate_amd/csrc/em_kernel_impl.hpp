@@ -210,19 +210,20 @@ enum { BF_F1 = 1, BF_F2 = 2, BF_F4 = 4, BF_F8 = 8, BF_TAIL = 16, BF_INRANGE = 32
 
 // dwords of padding between the 64-byte boundary and the EM loop, per instantiation and build (see the loop head);
 // -DCOLATE_LOOP_PAD=n overrides all of them (tools/pad_sweep.sh)
-constexpr int em_loop_pad(int mode, int nch, int erows, bool tput) {
+constexpr int em_loop_pad(int mode, int nch, int erows, bool tput, int wpe) {
 #ifdef COLATE_LOOP_PAD
   return (COLATE_LOOP_PAD) & 7;
 #else
-  (void)erows;
+  (void)erows, (void)wpe;
   if (mode != 0) return 0;
   // measured on MI355X, kernel ms for pads 0..7, loop code of round 3 (gpurun_out/r03j/padsweep.txt -> profiles/r03_placement.txt).
   // The pad shifts everything behind it, the loops compiled per kind of wave included.
 #ifdef COLATE_EM_ILP_BUILD
   (void)tput;
-  // latency variant, max-ilp build: E=23 B=100 1.015 1.036 1.017 1.033 1.028 1.031 1.027 1.028;
-  // E=122 B=100 1.378 1.355 1.370 1.355 1.356 1.363 1.364 1.375
-  return nch == 1 ? 0 : 3;
+  // latency variant, max-ilp build, kernel ms for pads 0..7 (gpurun_out/r03n, r03o -> profiles/r03_placement.txt):
+  // E=23 B=100 (the build without the register cap) 1.029 1.031 1.016 1.030 1.006 1.025 1.034 1.035;
+  // E=23 B=400 (with it) 1.237 1.238 1.238 1.254 1.247 1.255 1.247 1.243; E=122 B=100 1.363 1.372 1.361 1.379 1.368 1.367 1.371 1.344
+  return nch == 1 ? (wpe == 2 ? 4 : 2) : 7;
 #else
   (void)nch;
   if (!tput) return 6;  // latency variant, default build (not picked by colate_em_variant any more; COLATE_EM_VARIANT=latency)
@@ -250,11 +251,12 @@ constexpr int em_loop_pad2(int mode, int nch, bool tput) {
 // through the bin groups one after the other, their per-bin statics re-read from LDS: a third of the wave
 // slots and fewer registers per replicate, so three times as many replicates are resident per CU and fill
 // the issue slots that a lone workgroup leaves empty at its barriers.
-template <int MODE, int NCH, int EROWS, bool TPUT>
 // (second launch bound = waves per SIMD the register allocation must leave room for: three at up to 64 epochs -- two 6-wave
 // workgroups of the latency variant, six 2-wave ones of the throughput variant per CU: B = 400 ran 2.01 instead of 1.21 ms
-// when the tail model's refresh block took the kernel to 182 registers -- two at up to 128, one beyond)
-__global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, (NCH == 1) ? 3 : (NCH == 2 ? 2 : 1)) void em_kernel(ColateEmArgs p) {
+// when the tail model's refresh block took the kernel to 182 registers -- two at up to 128, one beyond.  WPE != 0 overrides
+// it: a batch that leaves every workgroup a CU to itself runs the build without the cap, 0.5 % faster at B = 100.)
+template <int MODE, int NCH, int EROWS, bool TPUT, int WPE = 0>
+__global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE : ((NCH == 1) ? 3 : (NCH == 2 ? 2 : 1))) void em_kernel(ColateEmArgs p) {
   extern __shared__ double lds[];
   const int E = p.E, A = p.A;
   constexpr int EPAD = NCH * kWave;
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, (NCH == 1) 
   // 1.362 .. 1.430 ms at B = 100; profiles/r02_placement.txt) -- and every edit of the prologue used to shift it.  The loop
   // is therefore pinned to a 64-byte boundary plus em_loop_pad() dwords, tuned per instantiation on the GPU.
   {
-    constexpr int kPad = em_loop_pad(MODE, NCH, EROWS, TPUT);
+    constexpr int kPad = em_loop_pad(MODE, NCH, EROWS, TPUT, WPE);
 #define COLATE_PAD_CASE(n) \
   if constexpr (kPad == n) asm volatile(".p2align 6\n\t.rept " #n "\n\ts_nop 0\n\t.endr");
     COLATE_PAD_CASE(0) COLATE_PAD_CASE(1) COLATE_PAD_CASE(2) COLATE_PAD_CASE(3)
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, (NCH == 1) 
         loc[0] = 0.0;
 #pragma unroll
         for (int c = 1; c < NCH; c++) loc[c] = loc[c - 1] + x_e[c - 1];
-        const double tot = loc[NCH - 1] + x_e[NCH - 1];
+        const double tot = (NCH == 1) ? x_e[0] : loc[NCH - 1] + x_e[NCH - 1];  // (no `0.0 + x` on the chain)
 #if COLATE_ABL_HAS(11)
         const double incl = tot * 7.0;
 #else
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, (NCH == 1) 
 #endif
         const double excl = dpp_d<WAVE_SHR1, 0xf, true>(0.0, incl);
 #pragma unroll
-        for (int c = 0; c < NCH; c++) cs_e[c] = excl + loc[c];
+        for (int c = 0; c < NCH; c++) cs_e[c] = (c == 0) ? excl : excl + loc[c];
       }
       COLATE_STAMP(8)
       if (ROLE == 0) {
@@ -940,7 +942,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, (NCH == 1) 
 #pragma unroll
         for (int c = NCH - 2; c >= 0; c--) ls[c] = ls[c + 1] + w[c + 1];
         {
-          const double tot = ls[0] + w[0];
+          const double tot = (NCH == 1) ? w[0] : ls[0] + w[0];
 #if COLATE_ABL_HAS(9)
           const double sR = tot * 3.0;
 #else
@@ -948,7 +950,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, (NCH == 1) 
 #endif
           const double excl = dpp_d<WAVE_SHL1, 0xf, true>(0.0, sR);
 #pragma unroll
-          for (int c = 0; c < NCH; c++) RSn[c] = excl + ls[c];
+          for (int c = 0; c < NCH; c++) RSn[c] = (c == NCH - 1) ? excl : excl + ls[c];
         }
         COLATE_STAMP(11)
 #pragma unroll
@@ -1223,7 +1225,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, (NCH == 1) 
       // scalar mask arithmetic, so that one compare and one branch decide.  With NCH consecutive epochs per lane that is: every
       // slot's copying lanes are a prefix of the lanes, the prefixes do not grow with the slot, and slot 0's is at most one
       // lane longer than the last slot's.
-      unsigned long long bad = cpm[0] & ~((cpm[NCH - 1] << 1) | 1ull);
+      unsigned long long bad = (NCH == 1) ? 0ull : (cpm[0] & ~((cpm[NCH - 1] << 1) | 1ull));
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         bad |= cpm[c] & (cpm[c] + 1ull);
@@ -1529,9 +1531,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, (NCH == 1) 
 }
 
 
-template <int MODE, int NCH, int EROWS, bool TPUT>
+template <int MODE, int NCH, int EROWS, bool TPUT, int WPE = 0>
 hipError_t launch_one(const ColateEmArgs& args, hipStream_t stream, size_t lds, int threads) {
-  auto kern = em_kernel<MODE, NCH, EROWS, TPUT>;
+  auto kern = em_kernel<MODE, NCH, EROWS, TPUT, WPE>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1558,10 +1560,18 @@ inline size_t em_lds_bytes(int E, int A) {
 
 // the latency variant (a wave per role and bin group) for 1 or 2 epoch chunks; each translation unit that
 // includes this header gets its own copy, compiled with that unit's flags
-inline hipError_t launch_latency(const ColateEmArgs& args, hipStream_t stream) {
+// `alone`: every workgroup has a CU to itself (B <= #CUs): the register cap that keeps three waves per SIMD is not needed
+inline hipError_t launch_latency(const ColateEmArgs& args, hipStream_t stream, bool alone = false) {
   const size_t lds = em_lds_bytes(args.E, args.A);
   const int threads = em_threads(args.A);
   if (em_chunks(args.E) == 2) return launch_one<0, 2, 4, false>(args, stream, lds, threads);
+#ifdef COLATE_EM_ILP_BUILD
+  if (alone) switch (em_rows(args.E)) {
+    case 1: return launch_one<0, 1, 1, false, 2>(args, stream, lds, threads);
+    case 2: return launch_one<0, 1, 2, false, 2>(args, stream, lds, threads);
+    default: return launch_one<0, 1, 4, false, 2>(args, stream, lds, threads);
+  }
+#endif
   switch (em_rows(args.E)) {
     case 1: return launch_one<0, 1, 1, false>(args, stream, lds, threads);
     case 2: return launch_one<0, 1, 2, false>(args, stream, lds, threads);

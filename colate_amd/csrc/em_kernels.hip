@@ -11,7 +11,7 @@
 
 #include "em_kernel_impl.hpp"
 
-hipError_t colate_em_launch_latency_ilp(const ColateEmArgs& args, hipStream_t stream);  // em_kernels_ilp.hip
+hipError_t colate_em_launch_latency_ilp(const ColateEmArgs& args, hipStream_t stream, bool alone);  // em_kernels_ilp.hip
 
 size_t colate_em_lds_bytes(int E, int A) { return em_lds_bytes(E, A); }
 
@@ -69,7 +69,10 @@ hipError_t colate_em_launch(const ColateEmArgs& args, hipStream_t stream) {
     return launch_one<1, 4, 4, false>(args, stream, lds, threads);
   }
   switch (colate_em_variant(args.B, args.E)) {
-    case 0: return colate_em_launch_latency_ilp(args, stream);
+    case 0: {
+      const int cus = device_cus();
+      return colate_em_launch_latency_ilp(args, stream, cus > 0 && args.B <= cus);
+    }
     case 1: return launch_latency(args, stream);
   }
   if (nch == 4) return launch_one<0, 4, 4, true>(args, stream, lds, 2 * kWave);

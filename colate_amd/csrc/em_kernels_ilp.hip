@@ -6,4 +6,4 @@
 #define COLATE_EM_ILP_BUILD 1
 #include "em_kernel_impl.hpp"
 
-hipError_t colate_em_launch_latency_ilp(const ColateEmArgs& args, hipStream_t stream) { return launch_latency(args, stream); }
+hipError_t colate_em_launch_latency_ilp(const ColateEmArgs& args, hipStream_t stream, bool alone) { return launch_latency(args, stream, alone); }
