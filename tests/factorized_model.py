@@ -13,7 +13,11 @@ oracle/ on the CPU (tests/test_factorized_model.py) without a GPU.
 import numpy as np
 
 
-INTEG_RESIDUE = 4.0e-17  # per unit count
+# Round 2's mean model of the reference's `integ` rounding residue, per unit count.  The kernel keeps it for the shared kind only;
+# for the not-shared kind it now carries the tail model of DESIGN.md section 6 (absorbed log-sum-exp terms, clamp, rounding noise),
+# whose executable CPU statement is tools/study/residue_models.cpp (model 5).  On the tables of tests/test_factorized_model.py
+# (one E-step at well-conditioned rates) the two are indistinguishable.
+INTEG_RESIDUE = 4.0e-17
 
 
 def epoch_index(age_grid, epochs):
