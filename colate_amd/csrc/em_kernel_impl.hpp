@@ -60,7 +60,11 @@ enum { O_W = 0, O_N, O_D, kNumBinArrays };  // per-bin values -> epochs: weight 
 enum { G_LAM = 0, G_INV, G_XA, G_P, G_BETA, G_CS, G_S, G_PW, kNumGather };  // per-epoch values in LDS
 constexpr int G_Q = kNumGather;  // one more row, q_e, only with two or more epoch chunks (the split leaders of em_kernel hand it over)
 constexpr int num_gather_rows(int nch) { return nch >= 2 ? kNumGather + 1 : kNumGather; }
-constexpr int tail_scratch_arrays(int nch) { return nch >= 2 ? 3 : 0; }  // with chunks split over waves the tail model's refresh cannot borrow the tile
+// with the epochs split over two waves of a role the tail model's refresh cannot borrow the tile (the other owner may still be
+// loading its tails), and each owner needs arrays of its own (they run the refresh side by side, unsynchronised: sharing one set
+// would let the slower one's first pass overwrite what the faster one is searching)
+// (the throughput variant has one wave per role: one set)
+constexpr int tail_scratch_arrays(int nch, bool tput) { return nch >= 2 ? (tput ? 3 : 6) : 0; }
 
 // ----------------------------------------------------------------- lane plumbing
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -286,8 +290,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   double* s_ll = s_cnt + 2 * APZ;                    // [8] per-wave log-likelihood partials + [2] total counts per kind + oldest data epoch
   double* s_exptab = s_ll + 12;                      // [64] 2^(j/32) as hi, lo pairs for em::em_exp_t (em_math.hpp)
   double* s_age = s_exptab + em::kExpTableDoubles;   // [AP] age grid (throughput variant; the tail model's refresh)
-  double* s_tscr = s_age + AP;                       // [3][APZ] scratch of the tail model's refresh (two or more epoch chunks only)
-  int* s_kb = reinterpret_cast<int*>(s_tscr + tail_scratch_arrays(NCH) * APZ);  // [AP + 1] epoch of each bin
+  double* s_tscr = s_age + AP;                       // [2 owners][3][APZ] scratch of the tail model's refresh (two or more epochs per lane only)
+  int* s_kb = reinterpret_cast<int*>(s_tscr + tail_scratch_arrays(NCH, TPUT) * APZ);  // [AP + 1] epoch of each bin
   int* s_fail = s_kb + AP + 1;                       // [8] per-wave "a bin failed" flags
   int* s_misc = s_fail + 8;                          // [4] nzlo, nzhi, flags
   int* s_bflags = s_misc + 4;                        // [AP] packed per-position statics (throughput variant)
@@ -497,7 +501,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   // The wave that keeps the verdict's history masks in the M-step and writes the verdict and the rates at the end: a
   // wave of the second bin group when there is one (it sits out P1 and P3, so this is off the critical chain; on the
   // leaders it cost 3.5 % at E=23 and 7 % at E=122, profiles/r02_placement.txt), else wave 0.
-  const int verdict_wave = (!TPUT && NB >= 2) ? 2 : 0;
+  // (with two epochs per lane and two bin groups all four waves own epoch work -- the split below -- and wave 0 is the one with
+  // slack: its slot's scans need no hand-over from the other owner)
+  const int verdict_wave = (!TPUT && NB >= 2 && NCH != 2) ? 2 : 0;
   const bool tracker = (wave == verdict_wave);
   constexpr int erows = EROWS;  // 16-lane rows that hold epochs: a compile-time constant (skipping the cross-row
                                 // scan steps behind run-time uniform branches measured slower)
@@ -1059,12 +1065,13 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
                   const int e1 = __builtin_ctzll(small_w[c]) * NCH + c;
                   e_sm = e1 < e_sm ? e1 : e_sm;
                 }
-              // scratch: with one chunk this role's tile (its tails are in registers by now and the bin waves write it again
-              // only behind barriers 3 and 1); with more chunks the owners of a role run this refresh side by side (same
-              // inputs, same values) while the other may still be loading its tails, so it has arrays of its own
-              double* const s_tau = (NCH == 1) ? out_mine + O_W * APZ : s_tscr;
-              double* const s_PQ = (NCH == 1) ? out_mine + O_N * APZ : s_tscr + APZ;
-              double* const s_PM = (NCH == 1) ? out_mine + O_D * APZ : s_tscr + 2 * APZ;
+              // scratch: with one epoch per lane this role's tile (its tails are in registers by now and the bin waves write it
+              // again only behind barriers 3 and 1); with more, the owners of a role run this refresh side by side (same inputs,
+              // same values, not synchronised) while the other may still be loading its tails: each has arrays of its own
+              double* const scr = s_tscr + (kSplit ? kOwn * 3 * APZ : 0);
+              double* const s_tau = (NCH == 1) ? out_mine + O_W * APZ : scr;
+              double* const s_PQ = (NCH == 1) ? out_mine + O_N * APZ : scr + APZ;
+              double* const s_PM = (NCH == 1) ? out_mine + O_D * APZ : scr + 2 * APZ;
               const int nbt = NB * kWave;
               double carryQ = 0.0, carryM = 0.0, PDtot = 0.0;
               for (int g = 0; g < NB; g++) {  // the not-shared bins, youngest group first
@@ -1377,9 +1384,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
         if (split && grp <= 1) {
           if constexpr (NCH == 2) {
             if (grp == 0) {
-              COLATE_BOTH(C0, C2, C0)
+              COLATE_BOTH(C0, C2, C1)  // (wave 0: keeps the verdict's history in the split)
             } else {
-              COLATE_BOTH(C0, C3, C1)  // (wave 2: the tracker whenever NB >= 2)
+              COLATE_BOTH(C0, C3, C0)
             }
           }
         } else if (leader) {
@@ -1548,12 +1555,12 @@ inline int em_threads(int A) { return 2 * 64 * em_groups(A); }  // two roles (la
 inline int em_chunks(int E) { return E <= 64 ? 1 : (E <= 128 ? 2 : 4); }
 inline int em_rows(int E) { return E <= 16 ? 1 : (E <= 32 ? 2 : 4); }  // BASELINE's `--bins 3,7,0.2` gives E = 23
 
-inline size_t em_lds_bytes(int E, int A) {
+inline size_t em_lds_bytes(int E, int A, bool tput) {
   const size_t EPAD = (size_t)em_chunks(E) * kWave;
   const size_t AP = (size_t)em_groups(A) * kWave;
   const size_t APZ = AP + 2;
   const size_t doubles = (EPAD + 1) + num_gather_rows(em_chunks(E)) * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ + 12 +
-                         em::kExpTableDoubles + AP + tail_scratch_arrays(em_chunks(E)) * APZ;
+                         em::kExpTableDoubles + AP + tail_scratch_arrays(em_chunks(E), tput) * APZ;
   const size_t ints = (AP + 1) + 8 + 4 + AP;
   return doubles * sizeof(double) + ints * sizeof(int);
 }
@@ -1562,7 +1569,7 @@ inline size_t em_lds_bytes(int E, int A) {
 // includes this header gets its own copy, compiled with that unit's flags
 // `alone`: every workgroup has a CU to itself (B <= #CUs): the register cap that keeps three waves per SIMD is not needed
 inline hipError_t launch_latency(const ColateEmArgs& args, hipStream_t stream, bool alone = false) {
-  const size_t lds = em_lds_bytes(args.E, args.A);
+  const size_t lds = em_lds_bytes(args.E, args.A, false);
   const int threads = em_threads(args.A);
   if (em_chunks(args.E) == 2) return launch_one<0, 2, 4, false>(args, stream, lds, threads);
 #ifdef COLATE_EM_ILP_BUILD

@@ -13,7 +13,7 @@
 
 hipError_t colate_em_launch_latency_ilp(const ColateEmArgs& args, hipStream_t stream, bool alone);  // em_kernels_ilp.hip
 
-size_t colate_em_lds_bytes(int E, int A) { return em_lds_bytes(E, A); }
+size_t colate_em_lds_bytes(int E, int A) { return em_lds_bytes(E, A, false); }  // (the larger of the two variants' needs)
 
 // number of CUs of the current device (cached per ordinal; atomics: launches may come from several host threads)
 static int device_cus() {
@@ -60,10 +60,10 @@ int colate_em_variant(int B, int E) {
 }
 
 hipError_t colate_em_launch(const ColateEmArgs& args, hipStream_t stream) {
-  const size_t lds = em_lds_bytes(args.E, args.A);
   const int nch = em_chunks(args.E);
   if (args.mode == 1) {
     const int threads = em_threads(args.A);
+    const size_t lds = em_lds_bytes(args.E, args.A, false);
     if (nch == 1) return launch_one<1, 1, 4, false>(args, stream, lds, threads);
     if (nch == 2) return launch_one<1, 2, 4, false>(args, stream, lds, threads);
     return launch_one<1, 4, 4, false>(args, stream, lds, threads);
@@ -75,6 +75,7 @@ hipError_t colate_em_launch(const ColateEmArgs& args, hipStream_t stream) {
     }
     case 1: return launch_latency(args, stream);
   }
+  const size_t lds = em_lds_bytes(args.E, args.A, true);
   if (nch == 4) return launch_one<0, 4, 4, true>(args, stream, lds, 2 * kWave);
   if (nch == 2) return launch_one<0, 2, 4, true>(args, stream, lds, 2 * kWave);
   switch (em_rows(args.E)) {

@@ -69,8 +69,8 @@ def cls(op, args):
     return "other"
 
 
-kinds = {"C0, C2, C0": "role A (shared), split: even epochs (wave 0)", "C1, C2, C0": "role B (not shared), split: even epochs (wave 1)",
-         "C0, C3, C1": "role A, split: odd epochs, keeps the verdict history (wave 2)", "C1, C3, C0": "role B, split: odd epochs (wave 3)",
+kinds = {"C0, C2, C1": "role A (shared), split: even epochs, keeps the verdict history (wave 0)", "C1, C2, C0": "role B (not shared), split: even epochs (wave 1)",
+         "C0, C3, C0": "role A, split: odd epochs (wave 2)", "C1, C3, C0": "role B, split: odd epochs (wave 3)",
          "C0, C1, C0": "role A (shared) leader", "C1, C1, C0": "role B (not shared) leader",
          "C0, C0, C1": "role A second bin group, keeps the verdict history", "C1, C0, C0": "role B second bin group",
          "C0, C1, C1": "role A leader that also keeps the verdict history (one bin group only)", "C0, C0, C0": "role A further bin groups"}
