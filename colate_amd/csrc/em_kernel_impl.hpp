@@ -58,7 +58,7 @@ namespace {
 constexpr int kWave = 64;
 enum { O_W = 0, O_N, O_D, kNumBinArrays };  // per-bin values -> epochs: weight (c r | c u), own-epoch num, denom
 enum { G_LAM = 0, G_INV, G_XA, G_P, G_BETA, G_CS, G_S, G_PW, kNumGather };  // per-epoch values in LDS
-constexpr int G_Q = kNumGather;  // one more row, q_e, only with two or more epoch chunks (the split leaders of em_kernel hand it over)
+constexpr int G_Q = kNumGather;  // one more row, q_e, only with two or more epochs per lane (the split leaders of em_kernel hand it over)
 constexpr int num_gather_rows(int nch) { return nch >= 2 ? kNumGather + 1 : kNumGather; }
 // with the epochs split over two waves of a role the tail model's refresh cannot borrow the tile (the other owner may still be
 // loading its tails), and each owner needs arrays of its own (they run the refresh side by side, unsynchronised: sharing one set
@@ -247,8 +247,8 @@ constexpr int em_loop_pad2(int mode, int nch, bool tput) {
 #endif
 }
 
-// MODE 0: EM to convergence, 1: one E-step (num/den/ll out).  NCH = epoch chunks of 64 per lane;
-// EROWS = 16-lane rows of a chunk that hold epochs (1, 2 or 4; 4 whenever NCH > 1).
+// MODE 0: EM to convergence, 1: one E-step (num/den/ll out).  NCH = epochs per lane (1, 2, 4: up to 64, 128, 256 epochs);
+// EROWS = 16-lane rows that hold epochs (1, 2 or 4; 4 whenever NCH > 1).
 // TPUT = false: the latency variant described at the top (a wave per role and bin group, one workgroup per CU
 // in mind).  TPUT = true: the THROUGHPUT variant for batches far beyond the number of CUs: the same phases and
 // the same arithmetic (results are bit-identical), but one replicate is two waves (one per role) that walk
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
       row_hi[c] = r1;
     }
   }
-  bool more_rows[NCH];  // (wave-uniform) some epoch of the chunk spans more than three 16-lane rows
+  bool more_rows[NCH];  // (wave-uniform) some epoch of the slot spans more than three 16-lane rows
   bool third_row = false;  // ... more than two (the steady-state loops read two tail slots per epoch, not three)
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   for (int c = 0; c < NCH; c++)  // (only epochs up to the oldest bin with data: the flat ones behind it do not move at all)
     noisy_thr[c] = (double)(ep_of(c)) <= s_ll[10] ? kNoisyRatio * (dt_e[c] * (kIntegResidue * (s_ll[8] + s_ll[9]))) : 0.0;
   unsigned long long prev_fail = 0;
-  unsigned long long ep_mask[NCH];  // the lanes of each chunk that hold an epoch
+  unsigned long long ep_mask[NCH];  // the lanes that hold an epoch, per slot
 #pragma unroll
   for (int c = 0; c < NCH; c++) ep_mask[c] = ballot64(ep_on[c]);
   const double thr = 1.0 - p.rel_tol;
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
 #endif
           s_ep[G_P * EPAD + e] = p_e[c];
           s_ep[G_BETA * EPAD + e] = beta_e[c];
-          if (NCH >= 2) s_ep[G_Q * EPAD + e] = q_e[c];  // (the other chunk's owner needs it for the carry of the affine scan; the tail model)
+          if (NCH >= 2) s_ep[G_Q * EPAD + e] = q_e[c];  // (the other slot's owner needs it for the affine scan; the tail model)
         }
       }
     }
@@ -1034,12 +1034,12 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
             for (int c = 0; c < NCH; c++) {
               const int e = ep_of(c);
               const bool has = e < E - 1;  // (the last epoch has no dt_e * integ term)
-              // (split: the other chunk's p_e comes from the row its owner has written; the same bits as that owner's register)
+              // (split: the other slot's p_e comes from the row its owner has written; the same bits as that owner's register)
               const double pe = (kSplit && !own(c)) ? s_ep[G_P * EPAD + e] : p_e[c];
               We[c] = ep_on[c] ? s_ep[G_S * EPAD + e] * pe : 0.0;  // the fold's term of epoch e per unit S(age)
               S1[c] = has ? s_ep[G_S * EPAD + e + 1] : 1.0;
-              // mass beyond t_{e+1} per unit count of the earlier bins: exact with one chunk; with more, where a wave may
-              // own one chunk only, its lower bound S_{e+1} (every 1 / S(age) >= 1), so that all owners decide alike
+              // mass beyond t_{e+1} per unit count of the earlier bins: exact with one epoch per lane; with more, where a wave may
+              // own one slot only, its lower bound S_{e+1} (every 1 / S(age) >= 1), so that all owners decide alike
               const double Ie = (NCH == 1) ? q_e[c] * T[c] : S1[c] * (c_all - C0[c]);
               // no bin can be cut while S_{e+1} >= 1e-14 (tau_b <= 3 2^-53 max(cs e^-cs) + chain noise < 3e-16), and sum c D
               // (<= 1e-16 per unit count) is below 1e-12 of the mass while that is >= 1e-4 per unit count -- in the epochs
@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     // (a wave with an epoch spanning more than two rows of data bins stays in the general loop)
     // ... and the iterations from min_iter on (log-likelihood and stop test in every one) in a second set of loops
     // compiled the same way: runs on sparse tables go on for up to 1e5 iterations there (1.55 -> 1.31 us per iteration).
-    // Only up to 64 epochs: with two chunks of epochs the extra loops cost the steady ones 2.5 % (1.53 -> 1.57 ms at
+    // Only up to 64 epochs: with two epochs per lane the extra loops cost the steady ones 2.5 % (1.53 -> 1.57 ms at
     // E = 122, every code placement; profiles/r02_placement.txt) -- there the general loop takes over at min_iter.
 #define COLATE_STEADY_LL(R, L, T)                             \
   for (; iter < max_iter; iter++) {                           \
@@ -1348,7 +1348,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     }                                                                                  \
   }
 #ifndef COLATE_LL_MAX_NCH
-#define COLATE_LL_MAX_NCH 1  // (epoch chunks up to which the log-likelihood-phase loops are compiled, see below)
+#define COLATE_LL_MAX_NCH 1  // (epochs per lane up to which the log-likelihood-phase loops are compiled, see below)
 #endif
 #ifdef COLATE_NO_LL_LOOPS  // (A/B switch: the iterations from min_iter on in the general loop)
 #define COLATE_BOTH(R, L, T)                                  \
@@ -1376,7 +1376,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     // 65..128 epochs with at least two bin groups: the epoch work of a role is SPLIT over its first two waves -- the even
     // epochs (slot 0 of every lane) to the wave of bin group 0, the odd ones (slot 1) to that of bin group 1, which otherwise
     // sits out P1 and P3.  Each owner runs the (single) scans in full -- they need all epochs -- and the per-epoch work
-    // (exp, the N and D terms, the stores) for its own slot: per wave about what one chunk of 64 epochs costs.
+    // (exp, the N and D terms, the stores) for its own slot: per wave about what 64 epochs cost.
     // any_more_rows / third_row are functions of the epochs' bin spans only, the same in every wave, so all four choose alike.
     const bool split = (NCH == 2) && !TPUT && NB >= 2;
     if (!(any_more_rows || third_row)) {
@@ -1565,7 +1565,7 @@ inline size_t em_lds_bytes(int E, int A, bool tput) {
   return doubles * sizeof(double) + ints * sizeof(int);
 }
 
-// the latency variant (a wave per role and bin group) for 1 or 2 epoch chunks; each translation unit that
+// the latency variant (a wave per role and bin group) for 1 or 2 epochs per lane; each translation unit that
 // includes this header gets its own copy, compiled with that unit's flags
 // `alone`: every workgroup has a CU to itself (B <= #CUs): the register cap that keeps three waves per SIMD is not needed
 inline hipError_t launch_latency(const ColateEmArgs& args, hipStream_t stream, bool alone = false) {
