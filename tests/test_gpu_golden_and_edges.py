@@ -167,7 +167,7 @@ def test_l3_cli_drop_in(ca, name, tmp_path):
     # reference's own rate there moves by ~1 % under libm noise (stable_mask).  Everything the checker finds pinned must
     # be the reference's token; the CLI's note must cover at least the epochs the checker finds unstable.
     unstable = ep.size - mask.sum(axis=1)
-    assert mask.mean() > 0.85
+    assert mask.mean() > 0.88, mask.mean()  # (measured: 0.895 for l3_coal_modern, 0.942 for l3_modern, 1.0 for the others)
     note = [l for l in err.split("\n") if l.startswith("Note: the last ")]
     k_cli = int(note[0].split()[3]) if note else 0
     assert unstable.max() - 1 <= k_cli <= unstable.max() + 3, (k_cli, unstable)
@@ -243,7 +243,8 @@ def test_iteration_limits_around_the_loop_hand_overs(ca, bins):
         assert (fl0 == ca.status_flags(fl1)).all(), (kw, fl0, fl1)
         assert np.allclose(ll1, ll0, rtol=1e-11, atol=0), kw
         mask = ol.stable_mask(grid, csh, cns, ep, r0, **kw)
-        assert mask.mean() > 0.8 and _rel(r1, r0)[mask].max() < RATE_RTOL, (kw, _rel(r1, r0)[mask].max())
+        # (the checker's stable fraction, measured: 0.971 at 23 epochs, 0.844 .. 0.852 at 122)
+        assert mask.mean() > (0.96 if ep.size < 64 else 0.84) and _rel(r1, r0)[mask].max() < RATE_RTOL, (kw, mask.mean(), _rel(r1, r0)[mask].max())
 
 
 def test_properties_at_baseline_sizes(ca):
@@ -467,12 +468,13 @@ def test_zero_starting_rates_and_failing_normalisers(ca, bins):
         assert np.allclose(ll1, ll0, rtol=1e-11, atol=0), (zero, ll0, ll1)
         assert ((r0 == 0) == (r1 == 0)).all(), zero
         mask = ol.stable_mask(grid, csh, cns, ep, r0, **kw)
-        assert mask.mean() > 0.7 and _rel(r1, r0)[mask].max() < RATE_RTOL, (zero, mask.mean(), _rel(r1, r0)[mask].max())
+        # (measured: 1.0 at 23 epochs, 0.861 at 122)
+        assert mask.mean() > (0.99 if ep.size < 64 else 0.85) and _rel(r1, r0)[mask].max() < RATE_RTOL, (zero, mask.mean(), _rel(r1, r0)[mask].max())
 
 
 def test_device_bootstrap_bit_identical_to_host(ca):
     """Block bootstrap on the GPU (weighted block sums + F redistribution, coal.cpp:3358-3441) against
-    the host path, same std::mt19937 weights: bit-identical tables, then EM straight from HBM."""
+    the host path and against the oracle, same std::mt19937 weights: bit-identical tables, then EM straight from HBM."""
     import torch
 
     rng = np.random.default_rng(5)
@@ -497,6 +499,17 @@ def test_device_bootstrap_bit_identical_to_host(ca):
             torch.cuda.synchronize()
             assert int(status.item()) == 0
             assert np.array_equal(d_sh.cpu().numpy(), h_sh) and np.array_equal(d_ns.cpu().numpy(), h_ns)
+            # ... and against the ORACLE directly (its own mt19937 + block weights + weighted sums + F redistribution)
+            import ctypes
+
+            g = (ctypes.c_uint * 625)()
+            ol.O.oracle_mt_seed(g, 777)
+            for i in range(nboot):
+                wo = np.zeros(nb)
+                ol.O.oracle_block_weights(g, nb, nboot, ol.P(wo))
+                o_sh, o_ns = np.zeros(A), np.zeros(A)
+                ol.O.oracle_bootstrap_counts(nb, A, ol.P(grid), age, ol.P(wo), ol.P(sh), ol.P(ns), ol.P(she), ol.P(nse), ol.P(o_sh), ol.P(o_ns))
+                assert np.array_equal(d_sh[i].cpu().numpy(), o_sh) and np.array_equal(d_ns[i].cpu().numpy(), o_ns)
     # and on into the EM without leaving HBM
     ep, _ = ol.epochs_from_bins("3,7,0.2")
     E = ep.size

@@ -134,7 +134,8 @@ def test_every_kernel_instantiation(ca, bins, E_expect):
     assert (it0 == it1).all() and ((fl0 & 3) == 0).all() and (fl0 == ca.status_flags(fl1)).all()
     assert np.allclose(ll1, ll0, rtol=1e-12, atol=0)
     mask = ol.stable_mask(grid, csh, cns, ep, r0, **kw)
-    assert mask.mean() > 0.8
+    # (the checker's own stable fraction, measured: 1.0 up to 64 epochs, 0.86 / 0.87 at 202 / 249 epochs)
+    assert mask.mean() > (0.99 if ep.size <= 64 else 0.85), mask.mean()
     assert _rel(r1, r0)[mask].max() < RATE_RTOL
     # one E-step at the rates the EM arrived at
     num, den, ll, flags = ca.em_estep(grid, csh, cns, ep, r0)
@@ -165,7 +166,7 @@ def test_sparse_tables_and_the_integ_residue(ca):
     assert (it0 == it1).all() and it0.max() > 1001
     assert np.allclose(ll1, ll0, rtol=1e-11, atol=0)
     mask = ol.stable_mask(grid, csh, cns, ep, r0)
-    assert mask.mean() > 0.9
+    assert mask.mean() > 0.93, mask.mean()  # (measured: 0.938)
     ol.check_rates(r1, fl1, r0, mask, RATE_RTOL)
     # the regime is really there: resolved epochs at the floor right behind a rate above 1e-3, in several replicates
     floor_behind_spike = [(r0[b, 1:] == 5e-9) & mask[b, 1:] & (np.maximum.accumulate(r0[b, :-1]) > 1e-3) for b in range(len(idx))]
