@@ -116,3 +116,17 @@ def test_worker_threads_release_their_workspace(ca):
         t = threading.Thread(target=work)
         t.start(), t.join()
     assert base - free_bytes() < 40 << 20, (base, free_bytes())  # 12 leaked workspaces would be > 140 MB
+
+
+def test_two_ranks_on_one_gpu_fail_cleanly(ca, tmp_path):
+    """On a one-GPU box `--ranks 2` puts both ranks on device 0, which RCCL refuses (ncclCommInitRank: invalid usage):
+    both ranks must report that and the launcher must return non-zero promptly -- no hang, no .coal."""
+    import time
+
+    if ca.device_count() != 1:
+        pytest.skip("one-GPU box only (with two GPUs the run succeeds: test_cli_two_gpus_equal_one)")
+    _, args = _stage(tmp_path)
+    t0 = time.time()
+    r = _run(args + ["--ranks", "2"], tmp_path, COLATE_RANK_GRACE_SEC="5")
+    assert r.returncode != 0 and time.time() - t0 < 120, (r.returncode, r.stderr[-500:])
+    assert "rank" in r.stderr and not (tmp_path / "mine.coal").exists()
