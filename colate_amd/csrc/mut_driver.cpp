@@ -24,6 +24,7 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -325,7 +326,8 @@ class MutPrefetcher {
  public:
   explicit MutPrefetcher(std::vector<std::string> files) : files_(std::move(files)), slots_(files_.size()) {
     const unsigned hc = std::thread::hardware_concurrency();
-    const int nthreads = (hc >= 6 && files_.size() > 1) ? 2 : 1;
+    int nthreads = (hc >= 6 && files_.size() > 1) ? (hc >= 12 ? 4 : 2) : 1;
+    if (const char* e = std::getenv("COLATE_THREADS")) nthreads = std::atoi(e) <= 1 ? 1 : std::min(nthreads, std::atoi(e));
     for (int t = 0; t < nthreads; t++)
       workers_.emplace_back([this] {
         for (;;) {
@@ -371,7 +373,7 @@ class MutPrefetcher {
   }
 
  private:
-  static constexpr size_t kAhead = 3;
+  static constexpr size_t kAhead = 5;
   struct Slot {
     std::vector<MutRow> rows;
     bool ready = false;
@@ -411,21 +413,46 @@ struct TmpStream {
   int bp = 0;
   char anc = 0, der = 0;
   int AAF = 0, DAF = 0;  // the reference resets these two between SNPs (coal.cpp:2182-2183)
-  // returns false at end of file, leaving every field as it was (coal.cpp:2126 `break`)
+  // returns false at end of file, leaving every field as it was (coal.cpp:2126 `break`).  The seven fread calls of the
+  // reference per record, served from a buffer of our own (40 M records x 7 library calls were 3 s of the table fill); a
+  // field cut short by the end of the file keeps the bytes that were there, as with fread.
   bool next() {
     int lchrom = 0;
-    if (!fp || std::fread(&lchrom, sizeof(int), 1, fp) != 1) return false;
+    if (!fp || get(&lchrom, sizeof(int)) != sizeof(int)) return false;
     char buf[1024];
     if (lchrom < 0 || lchrom > 1023) lchrom = 0;
-    std::fread(buf, sizeof(char), (size_t)lchrom, fp);
+    get(buf, (size_t)lchrom);
     chrom.assign(buf, (size_t)lchrom);
-    std::fread(&bp, sizeof(int), 1, fp);
-    std::fread(&anc, sizeof(char), 1, fp);
-    std::fread(&der, sizeof(char), 1, fp);
-    std::fread(&AAF, sizeof(int), 1, fp);
-    std::fread(&DAF, sizeof(int), 1, fp);
+    get(&bp, sizeof(int));
+    get(&anc, 1);
+    get(&der, 1);
+    get(&AAF, sizeof(int));
+    get(&DAF, sizeof(int));
     return true;
   }
+
+ private:
+  size_t get(void* dst, size_t n) {
+    if (end_ - pos_ < n) refill();
+    const size_t k = std::min(n, end_ - pos_);
+    std::memcpy(dst, buf_.data() + pos_, k);
+    pos_ += k;
+    return k;
+  }
+  void refill() {
+    if (buf_.empty()) buf_.resize(1u << 20);
+    const size_t keep = end_ - pos_;
+    if (keep) std::memmove(buf_.data(), buf_.data() + pos_, keep);
+    pos_ = 0, end_ = keep;
+    if (!eof_) {
+      const size_t got = std::fread(buf_.data() + end_, 1, buf_.size() - end_, fp);
+      end_ += got;
+      if (got == 0) eof_ = true;
+    }
+  }
+  std::vector<char> buf_;
+  size_t pos_ = 0, end_ = 0;
+  bool eof_ = false;
 };
 
 struct BlockTables {  // one entry per genome block; emp = row 0 of the reference's A*A tables
@@ -469,9 +496,12 @@ class SamplePool {
     for (int i = 0; i < nthreads; i++) workers_.emplace_back([this] { run(); });
   }
   ~SamplePool() { finish(); }
+  double waited_ = 0;  // seconds submit() waited for room
   void submit(SampleJob&& j) {
+    const double t0 = StageTimes::now();
     std::unique_lock<std::mutex> lk(m_);
     cv_room_.wait(lk, [this] { return q_.size() < 2 * workers_.size() + 2; });  // bounds the uniforms held in memory
+    waited_ += StageTimes::now() - t0;
     q_.push_back(std::move(j));
     cv_work_.notify_one();
   }
@@ -563,6 +593,70 @@ inline bool canonical_fast_ok() {
   return ok;
 }
 
+// std::mt19937's recurrence with the state regenerated 624 words at a time in loops the compiler vectorises (the library's
+// operator() does the same work word by word: 7.5 ns per word on the build container, against ~2 here).  Same sequence by
+// construction; UniformStream checks it against the library's generator before it trusts it.  State goes in and out of a
+// std::mt19937 through its textual form (the 624 words and the position, [rand.eng.mers]).
+class BulkMt19937 {
+ public:
+  bool load(const std::mt19937& g) {
+    std::ostringstream os;
+    os << g;
+    std::istringstream is(os.str());
+    for (int i = 0; i < 624; i++)
+      if (!(is >> x_[i])) return false;
+    if (!(is >> p_) || p_ > 624) return false;
+    return true;
+  }
+  bool store(std::mt19937& g) const {
+    std::ostringstream os;
+    for (int i = 0; i < 624; i++) os << x_[i] << ' ';
+    os << p_;
+    std::istringstream is(os.str());
+    return static_cast<bool>(is >> g);
+  }
+  // the next n 32-bit outputs
+  void generate(uint32_t* out, size_t n) {
+    while (n) {
+      if (p_ >= 624) twist();
+      const size_t k = std::min(n, (size_t)(624 - p_));
+      const uint32_t* x = x_ + p_;
+      for (size_t i = 0; i < k; i++) {  // tempering
+        uint32_t y = x[i];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        out[i] = y;
+      }
+      out += k, n -= k, p_ += (uint32_t)k;
+    }
+  }
+  void discard(unsigned long long n) {
+    uint32_t tmp[624];
+    while (n) {
+      const size_t k = (size_t)std::min<unsigned long long>(n, 624);
+      generate(tmp, k);
+      n -= k;
+    }
+  }
+
+ private:
+  static uint32_t mix(uint32_t a, uint32_t b) {
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  }
+  void twist() {
+    for (int i = 0; i < 227; i++) x_[i] = x_[i + 397] ^ mix(x_[i], x_[i + 1]);          // (old words only)
+    for (int i = 227; i < 454; i++) x_[i] = x_[i - 227] ^ mix(x_[i], x_[i + 1]);        // (new words of the first loop)
+    for (int i = 454; i < 623; i++) x_[i] = x_[i - 227] ^ mix(x_[i], x_[i + 1]);        // (new words of the second)
+    x_[623] = x_[396] ^ mix(x_[623], x_[0]);
+    p_ = 0;
+  }
+  uint32_t x_[624];
+  uint32_t p_ = 624;
+};
+
 // The uniforms themselves, on a thread of their own: the stream does not depend on the data, only HOW MANY of its values the
 // fill takes does.  The thread runs ahead on a copy of the run's generator, filling chunks of kChunk doubles, and keeps the
 // generator state at the start of every chunk; when the fill is over, the run's generator is set to the state at the start of
@@ -570,7 +664,20 @@ inline bool canonical_fast_ok() {
 class UniformStream {
  public:
   static constexpr size_t kChunk = 1u << 18;  // doubles per chunk (2 MB)
-  UniformStream(const std::mt19937& start, bool fast) : gen_(start), fast_(fast) {
+  UniformStream(const std::mt19937& start, bool fast) : gen_(start), first_(start) {
+    // the bulk generator only if it reproduces this machine's library on the run's own state
+    bulk_ok_ = fast && bulk_.load(start);
+    if (bulk_ok_) {
+      BulkMt19937 probe = bulk_;
+      std::mt19937 lib = start;
+      std::uniform_real_distribution<double> d(0, 1);
+      uint32_t w[2 * 1300];
+      probe.generate(w, 2 * 1300);  // (across two regenerations of the state)
+      for (int i = 0; i < 1300 && bulk_ok_; i++) bulk_ok_ = (d(lib) == canonical_from(w[2 * i], w[2 * i + 1]));
+      std::mt19937 back;
+      bulk_ok_ = bulk_ok_ && probe.store(back) && back == lib;
+    }
+    fast_ = fast;
     worker_ = std::thread([this] { run(); });
   }
   ~UniformStream() { stop(); }
@@ -586,26 +693,45 @@ class UniformStream {
   std::mt19937 state_after_taken() {
     stop();
     if (!cur_) return first_;
+    if (bulk_ok_) {
+      BulkMt19937 b = cur_->bulk_at_start;
+      b.discard(2 * (unsigned long long)pos_);  // two 32-bit draws per uniform (generate_canonical<double, 53>)
+      std::mt19937 g;
+      if (b.store(g)) return g;
+    }
     std::mt19937 g = cur_->at_start;
-    g.discard(2 * (unsigned long long)pos_);  // two 32-bit draws per uniform (generate_canonical<double, 53>)
+    g.discard(2 * (unsigned long long)pos_);
     return g;
   }
 
  private:
+  static double canonical_from(uint32_t r1, uint32_t r2) {
+    double ret = ((double)r1 + (double)r2 * 4294967296.0) * 0x1p-64;
+    if (ret >= 1.0) ret = std::nextafter(1.0, 0.0);
+    return ret;
+  }
   struct Chunk {
     std::mt19937 at_start;
+    BulkMt19937 bulk_at_start;
     std::vector<double> u;
   };
   void run() {
     std::uniform_real_distribution<double> d(0, 1);
+    std::vector<uint32_t> words(bulk_ok_ ? 2 * kChunk : 0);
     for (;;) {
       std::unique_ptr<Chunk> c(new Chunk);
-      c->at_start = gen_;
       c->u.resize(kChunk);
-      if (fast_)
-        for (size_t i = 0; i < kChunk; i++) c->u[i] = canonical_fast(gen_);
-      else
-        for (size_t i = 0; i < kChunk; i++) c->u[i] = d(gen_);
+      if (bulk_ok_) {
+        c->bulk_at_start = bulk_;
+        bulk_.generate(words.data(), 2 * kChunk);
+        for (size_t i = 0; i < kChunk; i++) c->u[i] = canonical_from(words[2 * i], words[2 * i + 1]);
+      } else {
+        c->at_start = gen_;
+        if (fast_)
+          for (size_t i = 0; i < kChunk; i++) c->u[i] = canonical_fast(gen_);
+        else
+          for (size_t i = 0; i < kChunk; i++) c->u[i] = d(gen_);
+      }
       std::unique_lock<std::mutex> lk(m_);
       cv_room_.wait(lk, [this] { return ready_.size() < 8 || stop_; });
       if (stop_) return;
@@ -614,8 +740,10 @@ class UniformStream {
     }
   }
   void next_chunk() {
+    const double t0 = StageTimes::now();
     std::unique_lock<std::mutex> lk(m_);
     cv_ready_.wait(lk, [this] { return !ready_.empty(); });
+    waited_ += StageTimes::now() - t0;
     cur_ = std::move(ready_.front());
     ready_.pop_front();
     pos_ = 0;
@@ -629,9 +757,15 @@ class UniformStream {
     cv_room_.notify_all();
     if (worker_.joinable()) worker_.join();
   }
+ public:
+  double waited_ = 0;  // seconds the fill waited for uniforms
+  bool bulk() const { return bulk_ok_; }
+
+ private:
   std::mt19937 gen_;
-  const std::mt19937 first_ = gen_;
-  const bool fast_;
+  const std::mt19937 first_;
+  BulkMt19937 bulk_;
+  bool bulk_ok_ = false, fast_ = false;
   std::thread worker_;
   std::mutex m_;
   std::condition_variable cv_ready_, cv_room_;
@@ -691,7 +825,7 @@ int fill_tables_impl(const std::vector<std::string>& chr_names,
   };
 
   std::vector<MutRow> rows_local;
-  std::string tar_mask, ref_mask, ancestral, derived;
+  std::string tar_mask, ref_mask;
   std::unique_ptr<MutPrefetcher> prefetch;
   if (!mut_cache) prefetch.reset(new MutPrefetcher(mut_files));
   for (size_t chr = 0; chr < mut_files.size(); chr++) {
@@ -723,20 +857,22 @@ int fill_tables_impl(const std::vector<std::string>& chr_names,
     for (const MutRow& m : rows) {
       if (!(m.flipped == 0 && m.num_branches == 1 && m.age_begin < m.age_end && m.age_end >= age))
         continue;
-      ancestral.clear();
-      derived.clear();
-      size_t i = 0;
-      while (i < m.mutation_type.size() && m.mutation_type[i] != '/') ancestral.push_back(m.mutation_type[i++]);
-      i++;
-      while (i < m.mutation_type.size()) derived.push_back(m.mutation_type[i++]);
+      // "anc/der" (mutations.cpp:236-246 splits at the first '/'): both sides as views into the row's string
+      const std::string& mt = m.mutation_type;
+      const size_t slash = mt.find('/');
+      const size_t anc_len = slash == std::string::npos ? mt.size() : slash;
+      const char* const anc_p = mt.data();
+      const char* const der_p = slash == std::string::npos ? mt.data() + mt.size() : mt.data() + slash + 1;
+      const size_t der_len = slash == std::string::npos ? 0 : mt.size() - slash - 1;
       const int bp_mut = m.pos;
-      if (ancestral.empty() || derived.empty()) continue;
+      if (anc_len == 0 || der_len == 0) continue;
+      const char anc0 = anc_p[0], der0 = der_p[0];
 
       bool use = true;
       if (has_tar_mask && (size_t)bp_mut < tar_mask.size() && tar_mask[bp_mut - 1] != 'P') use = false;
       if (has_ref_mask && (size_t)bp_mut < ref_mask.size() && ref_mask[bp_mut - 1] != 'P') use = false;
-      if (ancestral != "A" && ancestral != "C" && ancestral != "G" && ancestral != "T" && ancestral != "0") use = false;
-      if (derived != "A" && derived != "C" && derived != "G" && derived != "T" && derived != "1") use = false;
+      if (!(anc_len == 1 && (anc0 == 'A' || anc0 == 'C' || anc0 == 'G' || anc0 == 'T' || anc0 == '0'))) use = false;
+      if (!(der_len == 1 && (der0 == 'A' || der0 == 'C' || der0 == 'G' || der0 == 'T' || der0 == '1'))) use = false;
 
       if (use) {  // reference sample must carry the derived allele, coal.cpp:2181-2199
         ref.DAF = 0;
@@ -744,7 +880,7 @@ int fill_tables_impl(const std::vector<std::string>& chr_names,
         while (ref.chrom == name && ref.bp < bp_mut) {
           if (!ref.next()) break;
         }
-        if (ref.chrom != name || ref.bp != bp_mut || ref.anc != ancestral[0] || ref.der != derived[0]) use = false;
+        if (ref.chrom != name || ref.bp != bp_mut || ref.anc != anc0 || ref.der != der0) use = false;
       }
       if (ref.DAF == 0) use = false;
       const int N_ref = ref.DAF + ref.AAF;
@@ -755,7 +891,7 @@ int fill_tables_impl(const std::vector<std::string>& chr_names,
         while (tgt.chrom == name && tgt.bp < bp_mut) {
           if (!tgt.next()) break;
         }
-        if (tgt.chrom != name || tgt.bp != bp_mut || tgt.anc != ancestral[0] || tgt.der != derived[0]) use = false;
+        if (tgt.chrom != name || tgt.bp != bp_mut || tgt.anc != anc0 || tgt.der != der0) use = false;
       }
       const int N_target = tgt.DAF + tgt.AAF;
       if (N_target == 0) use = false;
@@ -820,8 +956,12 @@ int fill_tables_impl(const std::vector<std::string>& chr_names,
   if (tgt.fp) std::fclose(tgt.fp);
   if (ref.fp) std::fclose(ref.fp);
   if (pool) {
+    const double t0 = StageTimes::now();
     pool->finish();  // (before the tables are trimmed)
     rng = stream->state_after_taken();
+    if (g_times.on)
+      std::cerr << "Timing: table fill waited " << stream->waited_ << " s for uniforms (bulk generator " << (stream->bulk() ? "on" : "off")
+                << "), " << pool->waited_ << " s for room in the sampling queue, " << StageTimes::now() - t0 << " s for the last jobs" << std::endl;
   }
   tab.sh.resize(num_blocks);
   tab.ns.resize(num_blocks);
