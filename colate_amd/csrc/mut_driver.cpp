@@ -202,10 +202,17 @@ struct MutRow {
   std::string mutation_type = "NA";
 };
 
+// (the readers run on their own threads: leave without running the static destructors under the other threads' feet)
+[[noreturn]] void reader_exit() {
+  std::cerr.flush();
+  std::cout.flush();
+  std::fflush(nullptr);
+  std::_Exit(1);
+}
 [[noreturn]] void mut_line_error(const std::string& line) {
   std::cerr << "Error reading following line in mut file:" << std::endl;
   std::cerr << line << std::endl;
-  std::exit(1);
+  reader_exit();
 }
 
 // std::stoi on the text at p (leading white space, sign, digits; what follows the digits is ignored), without the copy
@@ -281,7 +288,7 @@ bool read_mut_file(const std::string& filename, std::vector<MutRow>& rows) {
   if (!f) f = gzopen((filename + ".gz").c_str(), "rb");
   if (!f) {
     std::cerr << "Error while reading " << filename << "(.gz)." << std::endl;
-    std::exit(1);  // mutations.cpp:265-268
+    reader_exit();  // mutations.cpp:265-268: exit(1)
   }
   gzbuffer(f, 1 << 20);
   rows.clear();
@@ -952,6 +959,7 @@ int fill_tables_impl(const std::vector<std::string>& chr_names,
     }
     advance_block();  // chromosome end, coal.cpp:2306-2310
     g_times.table_fill += StageTimes::now() - t_fill0;
+    if (pool && pool->redo()) break;  // (this pass is void: do not parse the rest for nothing)
   }
   if (tgt.fp) std::fclose(tgt.fp);
   if (ref.fp) std::fclose(ref.fp);
