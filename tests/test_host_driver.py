@@ -450,3 +450,23 @@ def test_threaded_table_fill_redoes_sequentially_when_a_sample_is_redrawn(tmp_pa
     threaded = _counts(tmp_path, 8)
     assert _counts.redone  # (the threaded pass gave up ...)
     assert threaded == _counts(tmp_path, 1)  # (... and the repeat is the sequential result)
+
+
+def test_malformed_mut_line_is_reported_from_the_reader_thread(tmp_path):
+    """mutations.cpp:77-246 exits with `Error reading following line in mut file` on a row it cannot parse; ours does the same
+    from its reader thread (exit code 1, the line echoed), threaded or not."""
+    import gzip
+
+    import synth_files
+
+    synth_files.write_inputs(str(tmp_path), chroms=("1", "2"), snps_per_chr=300, seed=9, gz=True)
+    p = tmp_path / "P_chr2.mut.gz"
+    lines = gzip.open(p, "rt").read().split("\n")
+    lines[50] = lines[50].replace(";", ";x", 2)  # the position field is no number any more
+    with gzip.open(p, "wt") as g:
+        g.write("\n".join(lines))
+    for threads in ("8", "1"):
+        r = subprocess.run([CLI, "--mode", "mut", "--mut", "P", "--target_tmp", "T.colate.in", "--reference_tmp", "R.colate.in", "--chr",
+                            "chr.txt", "--bins", "3,7,0.2", "--seed", "1", "--counts_only", "-o", "x"], cwd=str(tmp_path),
+                           capture_output=True, text=True, env=dict(os.environ, COLATE_THREADS=threads), timeout=60)
+        assert r.returncode == 1 and "Error reading following line in mut file" in r.stderr and lines[50] in r.stderr, r.stderr[-400:]
