@@ -58,8 +58,8 @@ namespace {
 constexpr int kWave = 64;
 enum { O_W = 0, O_N, O_D, kNumBinArrays };  // per-bin values -> epochs: weight (c r | c u), own-epoch num, denom
 enum { G_LAM = 0, G_INV, G_XA, G_P, G_BETA, G_CS, G_S, G_PW, kNumGather };  // per-epoch values in LDS
-constexpr int G_Q = kNumGather;  // one more row, q_e, only with two or more epochs per lane (the split leaders of em_kernel hand it over)
-constexpr int num_gather_rows(int nch) { return nch >= 2 ? kNumGather + 1 : kNumGather; }
+constexpr int G_Q = kNumGather;  // one more row, q_e: the split leaders of em_kernel hand it over; free mode: wave 3 to role B's leader
+constexpr int num_gather_rows(int nch, bool tput) { return (nch >= 2 || !tput) ? kNumGather + 1 : kNumGather; }
 // with the epochs split over two waves of a role the tail model's refresh cannot borrow the tile (the other owner may still be
 // loading its tails), and each owner needs arrays of its own (they run the refresh side by side, unsynchronised: sharing one set
 // would let the slower one's first pass overwrite what the faster one is searching)
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   // ---- LDS carve-up ----
   double* s_t = lds;                                 // [EPAD + 1] epoch starts
   double* s_ep = s_t + EPAD + 1;                     // [kNumGather][EPAD] epoch values (A writes CS,S,PW; B the rest)
-  constexpr int kRows = num_gather_rows(NCH);
+  constexpr int kRows = num_gather_rows(NCH, TPUT);
   double* s_out = s_ep + kRows * EPAD;               // [2 roles][kNumBinArrays][APZ] per-bin tails
   double* s_nd = s_out + 2 * kNumBinArrays * APZ;    // [2 roles][2][EPAD] partial N, D per role
   double* s_cfail = s_nd + 4 * EPAD;                 // [2 roles][APZ] counts of bins whose normaliser failed
@@ -507,6 +507,25 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   const bool tracker = (wave == verdict_wave);
   constexpr int erows = EROWS;  // 16-lane rows that hold epochs: a compile-time constant (skipping the cross-row
                                 // scan steps behind run-time uniform branches measured slower)
+  // One epoch per lane, latency variant: NO BARRIER between the epoch values and the bin terms.  The iteration is a chain
+  // of dependent latencies (LDS round trips, DPP steps), not of issue slots, and the hand-over "leader stores S_e -> wait ->
+  // barrier -> every bin gathers S_k" was ~150 cycles of it.  Instead every wave of role A runs the cs scan and S_e =
+  // exp(-cs_e) itself, in its epoch lanes (each wave has all rates: each runs the M-step), and its bins fetch S_k, 1 - S_k out
+  // of the wave's own registers (ds_bpermute: one trip through the LDS crossbar, no store, no barrier), like the rate; the
+  // bins' exp(-lambda_k (age - t_k)) fills the scan's stalls.  1 / lambda_k and (t_k + 1/lambda_k) lambda_k come from the
+  // bin's own division instead of the gathered per-epoch values (same operands, same bits).  A role-B bin needs nothing but
+  // its rate, so the waves of role B run straight from the M-step into their bin terms; role B's epoch values q_e, p_e,
+  // beta_e, needed in P3 only, are computed by the wave of its second bin group (wave 3) when there is one, which otherwise
+  // idles from its bin terms to the next M-step, and reach both leaders through LDS behind barrier 2.  The rows of S_e etc.
+  // are still written (by wave 0) for the readers behind barrier 2 -- and for the two cases in which a role-B bin does need
+  // them: the log-likelihood (cs_k) and a last rate of zero; then, and only then, barrier 1 is executed (both conditions are
+  // the same in every wave).  The loops compiled per kind of wave run while the last rate is positive and leave at the first
+  // iteration that ends with it at zero (the general loop, which tests it at run time, takes over).
+  // Measured on one box (gpurun_out/r03z -> profiles/r03_free_mode.txt): 0.990 against 1.000 ms at B = 100 -- and 1.279 against
+  // 1.238 ms at B = 400, where two workgroups share a CU and the instructions of the redundant scans (+8 % in total) are no
+  // longer free: the mode belongs to the build for batches that leave every workgroup a CU to itself (WPE == 2).
+  constexpr bool kFree = !TPUT && NCH == 1 && WPE == 2;
+  const int p1b_wave = (kFree && NB >= 2) ? 3 : 1;
   const int nwave_live = 2 * NB;
   (void)nwave_live;
 
@@ -558,9 +577,13 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   // The tail model (P3, role B leader) is refreshed in iterations 0, 1, 2, 4, 8, ... (powers of two) and held in between:
   // its inputs move fast while the rates leave their starting values and ever more slowly afterwards (tools/study/
   // residue_models.cpp: the final rates stay within the reference's own libm-noise spread of the per-iteration evaluation).
+  // free mode: the last rate is positive (after the latest M-step; the same in every wave) -- what the loops compiled per kind of
+  // wave assume; always true otherwise (those loops test it themselves where it matters)
+  bool last_pos = true;
+  if (kFree) last_pos = (ballot64(lam_e[0] > 0.0) >> (E - 1)) & 1ull;
   auto tail_due = [&](int it) { return (it & (it - 1)) == 0; };
   auto tail_next_due = [&](int it) { return it <= 1 ? it : (1 << (32 - __builtin_clz((unsigned)(it - 1)))); };  // first due iteration >= it
-  auto iteration = [&](auto role_c, auto leader_c, auto ll_c, auto track_c, auto refresh_c) __attribute__((always_inline)) -> bool {
+  auto iteration = [&](auto role_c, auto leader_c, auto ll_c, auto track_c, auto refresh_c, auto p1_c) __attribute__((always_inline)) -> bool {
     COLATE_STAMP(7)
     // (compile-time role / leadership / "no log-likelihood needed" in the steady-state loops below; -1 = run-time value)
     constexpr int kRole = decltype(role_c)::value, kLeader = decltype(leader_c)::value, kNeedLL = decltype(ll_c)::value;
@@ -576,16 +599,22 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     constexpr int kOwn = (kLeader == 3) ? 1 : 0;
     static_assert(!kSplit || NCH == 2, "the split is for two epochs per lane");
     auto own = [&](int c) { return !kSplit || c == kOwn; };
+    // which epoch values this wave computes in P1 -- bit 0: role A's (cs, S, 1 - S), bit 1: role B's (q, p, beta, ...); -1:
+    // decided at run time
+    constexpr int kP1 = decltype(p1_c)::value;
+    const bool P1A = kP1 < 0 ? (ROLE == 0 && (kFree || LEADER)) : ((kP1 & 1) != 0);
+    const bool P1B = kP1 < 0 ? (kFree ? wave == p1b_wave : (LEADER && ROLE == 1)) : ((kP1 & 2) != 0);
+    constexpr bool CROSS = kFree;  // the bins divide for themselves and fetch S_k from the wave's own registers
     const bool need_ll = kNeedLL < 0 ? ((MODE == 1) || (iter >= p.min_iter) || (iter == max_iter - 1) || p.ll_trace != nullptr) : (kNeedLL != 0);
     // ============================================================ P1: epoch values (ROLE leaders)
     double q_e[NCH], p_e[NCH], beta_e[NCH], S_e[NCH], omS_e[NCH], cs_e[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) q_e[c] = p_e[c] = beta_e[c] = S_e[c] = omS_e[c] = cs_e[c] = 0.0;
-    if (LEADER && !COLATE_ABL_HAS(15)) {
+    if ((P1A || P1B) && !COLATE_ABL_HAS(15)) {
       double x_e[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; c++) x_e[c] = lam_e[c] * dt_e[c];
-      if (ROLE == 0) {
+      if (P1A) {
         // cs_e = sum_{j<e} lambda_j dt_j (coal_EM.cpp:100-103): a lane's epochs are consecutive, so one wave scan of the
         // lanes' totals plus the local prefix (split: every owner runs it in full -- the rates of all epochs are in every
         // wave -- and keeps its own slot)
@@ -604,7 +633,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
         for (int c = 0; c < NCH; c++) cs_e[c] = (c == 0) ? excl : excl + loc[c];
       }
       COLATE_STAMP(8)
-      if (ROLE == 0) {
+      if (P1A) {
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           if (!own(c)) continue;
@@ -617,11 +646,14 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
 #endif
           // (no `if (ep_on)`: the rows are EPAD wide, entries beyond E are written with whatever the idle lanes hold and
           // never read for an epoch; a not-taken skip branch costs a lone wave 8 cycles, its exec bookkeeping 10 more)
-          s_ep[G_CS * EPAD + e] = cs_e[c];
-          s_ep[G_S * EPAD + e] = S_e[c];
-          s_ep[G_PW * EPAD + e] = omS_e[c];
+          if (!kFree || LEADER) {  // (free: every wave of role A has them in registers; wave 0 writes the rows)
+            s_ep[G_CS * EPAD + e] = cs_e[c];
+            s_ep[G_S * EPAD + e] = S_e[c];
+            s_ep[G_PW * EPAD + e] = omS_e[c];
+          }
         }
-      } else {
+      }
+      if (P1B) {
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           if (!own(c)) continue;
@@ -645,15 +677,17 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
           p_e[c] = valid ? 1.0 - q_e[c] : 0.0;                                  // exp(A_ep + cs), coal_EM.cpp:119
           beta_e[c] = valid ? (t_e[c] + inv) - (tn_e[c] + inv) * q_e[c] : 0.0;  // exp(B_ep + cs), coal_EM.cpp:120
           s_ep[G_LAM * EPAD + e] = lam_e[c];
-          s_ep[G_INV * EPAD + e] = inv;
+          if (!CROSS) {  // (crossed: the bins divide for themselves)
+            s_ep[G_INV * EPAD + e] = inv;
 #if COLATE_ABL_HAS(7)
-          s_ep[G_XA * EPAD + e] = (t_e[c] + inv) * lam_e[c];
+            s_ep[G_XA * EPAD + e] = (t_e[c] + inv) * lam_e[c];
 #else
-          s_ep[G_XA * EPAD + e] = em::em_div_known_rcp(t_e[c] + inv, inv, lam_e[c]);  // (t + 1/lambda)/(1/lambda), coal_EM.cpp:204
+            s_ep[G_XA * EPAD + e] = em::em_div_known_rcp(t_e[c] + inv, inv, lam_e[c]);  // (t + 1/lambda)/(1/lambda), coal_EM.cpp:204
 #endif
+          }
           s_ep[G_P * EPAD + e] = p_e[c];
           s_ep[G_BETA * EPAD + e] = beta_e[c];
-          if (NCH >= 2) s_ep[G_Q * EPAD + e] = q_e[c];  // (the other slot's owner needs it for the affine scan; the tail model)
+          if (NCH >= 2 || kFree) s_ep[G_Q * EPAD + e] = q_e[c];  // (the other slot's owner needs it for the affine scan; the tail model; free: role B's leader)
         }
       }
     }
@@ -662,7 +696,6 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     // the wait the barrier needs anyway) lets the bin's exp(-lambda_k (age - t_k)) start right behind the barrier instead
     // of behind the LDS gather of the other per-epoch values.  Same value, so nothing changes but the time.
     double lk_pre = 0.0;
-#ifndef COLATE_NO_LK_PREFETCH
     if (!TPUT) {
       const int kq = bs0.kb < E ? bs0.kb : 0;
 #pragma unroll
@@ -673,16 +706,27 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
       }
       asm volatile("" : "+v"(lk_pre));  // (keeps the fetch on this side of the barrier)
     }
-#endif
+    // free: the bin's S_k, 1 - S_k out of this wave's own epoch lanes, and its exp(-lambda_k (age - t_k)) -- outside the
+    // `live` branch of the bin terms, so that it shares a basic block with the scan and fills its stalls
+    double Sk_pre = 0.0, PWk_pre = 0.0, qd_pre = 0.0;
+    if (kFree && ROLE == 0) {
+      const int kq = bs0.kb < E ? bs0.kb : 0;
+      const int s_lo = __builtin_amdgcn_ds_bpermute((kq & 63) << 2, __double2loint(S_e[0]));
+      const int s_hi = __builtin_amdgcn_ds_bpermute((kq & 63) << 2, __double2hiint(S_e[0]));
+      const int o_lo = __builtin_amdgcn_ds_bpermute((kq & 63) << 2, __double2loint(omS_e[0]));
+      const int o_hi = __builtin_amdgcn_ds_bpermute((kq & 63) << 2, __double2hiint(omS_e[0]));
+      Sk_pre = __hiloint2double(s_hi, s_lo);
+      PWk_pre = __hiloint2double(o_hi, o_lo);
+      qd_pre = em::em_exp_t(-(lk_pre * bs0.da), s_exptab);
+    }
     COLATE_STAMP(9)
-    __syncthreads();  // ---- barrier 1: epoch values visible
-    COLATE_STAMP(0)
     // the last epoch absorbs (lambda_{E-1} > 0) in every valid run; the reference asserts it only
     // for bins inside the last epoch (coal_EM.cpp:351)
     // (from this wave's own copy of the rates -- every wave runs the M-step --, not from LDS: the read and its wait were the
     // first thing behind barrier 1 in role B's waves)
-    bool absorbing = false;
-    {
+    // (the free-mode loops compiled per kind of wave run only while it does: the loop conditions below)
+    bool absorbing = kFree && kSteady;
+    if (!(kFree && kSteady)) {
       const int cl = (E - 1) & (NCH - 1), ll_ = (E - 1) >> kSlotShift;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
@@ -690,8 +734,12 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
         if (NCH == 1 || c == cl) absorbing = (pos >> ll_) & 1ull;
       }
     }
+    // ---- barrier 1: epoch values visible (free: only where a role-B bin reads them -- see above; uniform over the workgroup)
+    if (!kFree || need_ll || !absorbing) __syncthreads();
+    COLATE_STAMP(0)
     // ============================================================ P2: bin terms (own bins, own ROLE)
-    auto bin_terms = [&](const BinStat& bs, const double lk_own, const bool have_lk) {
+    // (cross: free mode -- Sk_in, PWk_in, qd_in are this bin's S_k, 1 - S_k, exp(-lambda_k (age - t_k)) from above)
+    auto bin_terms = [&](const BinStat& bs, const double lk_own, const bool have_lk, const bool cross, const double Sk_in, const double PWk_in, const double qd_in) {
       const double a_b = bs.a_b, cnt = bs.cnt, tk = bs.tk, tkn = bs.tkn, dtk = bs.dtk, da = bs.da, db = bs.db;
       const double f1 = bs.f1, f2 = bs.f2, f4 = bs.f4, f8 = bs.f8;
       const int kb = bs.kb, pos = bs.pos;
@@ -700,7 +748,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
       double o_w = 0, o_N = 0, o_D = 0, llp = 0.0;
       bool fail = false;
       if (live && !COLATE_ABL_HAS(12)) {
-        const double lk = have_lk ? lk_own : s_ep[G_LAM * EPAD + kb], ik = s_ep[G_INV * EPAD + kb];
+        const double lk = have_lk ? lk_own : s_ep[G_LAM * EPAD + kb];
+        // 1 / lambda_k: the per-epoch value of P1, or the bin's own division (the same operation on the same operand)
+        const double ik = cross ? 1.0 / lk : s_ep[G_INV * EPAD + kb];
         const bool lpos = lk > 0;
         // -cumsum(age) at the merged grid (coal_EM.cpp:178-181): only the log-likelihood needs it
         auto neg_cs_age = [&]() {
@@ -709,11 +759,12 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
           return -(ck1 + lk * (a_b - a_b));  // (second copy of `age` in the merged grid)
         };
         if (ROLE == 0) {  // ---- EM_shared, coal_EM.cpp:198-210, 263-287
-          const double Sk = s_ep[G_S * EPAD + kb], Xak = s_ep[G_XA * EPAD + kb], PWk = s_ep[G_PW * EPAD + kb];
+          const double Sk = cross ? Sk_in : s_ep[G_S * EPAD + kb], PWk = cross ? PWk_in : s_ep[G_PW * EPAD + kb];
+          const double Xak = cross ? em::em_div_known_rcp(tk + ik, ik, lk) : s_ep[G_XA * EPAD + kb];  // (t_k + 1/lambda)/(1/lambda), coal_EM.cpp:204
 #if COLATE_ABL_HAS(5)
           const double qd = 1.0 - lk * da;
 #else
-          const double qd = em::em_exp_t(-(lk * da), s_exptab);  // exp(-cumsum(age) + cumsum(t_k)): same up to the rounding of cumsum
+          const double qd = cross ? qd_in : em::em_exp_t(-(lk * da), s_exptab);  // exp(-cumsum(age) + cumsum(t_k)): same up to the rounding of cumsum
 #endif
 #if COLATE_ABL_HAS(8)
           const double Y = (a_b + ik) * lk;
@@ -860,14 +911,10 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
         b.live = inr && b.cnt > 0;
         b.last_bin = (b.kb == E - 1);
         b.is_tail = fl & BF_TAIL;
-        bin_terms(b, 0.0, false);
+        bin_terms(b, 0.0, false, false, 0.0, 0.0, 0.0);
       }
     } else {
-#ifndef COLATE_NO_LK_PREFETCH
-      bin_terms(bs0, lk_pre, true);
-#else
-      bin_terms(bs0, 0.0, false);
-#endif
+      bin_terms(bs0, lk_pre, true, CROSS, Sk_pre, PWk_pre, qd_pre);
     }
     COLATE_STAMP(2)
     __syncthreads();  // ---- barrier 2: per-bin tails visible
@@ -906,6 +953,11 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
         }
 #endif
         if (ROLE == 0 && mine) {  // the shared leader also needs the not-shared leader's p_e, beta_e
+          p_e[c] = s_ep[G_P * EPAD + ep_of(c)];
+          beta_e[c] = s_ep[G_BETA * EPAD + ep_of(c)];
+        }
+        if (ROLE == 1 && mine && !P1B) {  // (free: role B's epoch values are wave 3's work)
+          q_e[c] = s_ep[G_Q * EPAD + ep_of(c)];
           p_e[c] = s_ep[G_P * EPAD + ep_of(c)];
           beta_e[c] = s_ep[G_BETA * EPAD + ep_of(c)];
         }
@@ -1272,6 +1324,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
         }
       }
     }
+    if (kFree && kSteady) last_pos = (ballot64(lam_e[0] > 0.0) >> (E - 1)) & 1ull;  // (for the loop conditions: see `kFree`)
     COLATE_STAMP(5)
     // stop rule, coal.cpp:3822 (evaluated after the update); uniform across the workgroup
     bool stop = false;
@@ -1295,22 +1348,22 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
     using CR = std::integral_constant<int, -1>;
-#define COLATE_STEADY(R, L, T)                                \
+#define COLATE_STEADY(R, L, T, P)                             \
   do {                                                        \
-    iteration(R{}, L{}, C0{}, T{}, C0{});                     \
-  } while (__builtin_expect(++iter < n_steady, 1))
+    iteration(R{}, L{}, C0{}, T{}, C0{}, P{});                \
+  } while (__builtin_expect(++iter < n_steady && last_pos, 1))
     // (the role B leader: the iterations that refresh the tail model are peeled out of the hot loop, which then carries
     // nothing of it but the held correction; same schedule as tail_due())
-#define COLATE_STEADY_B(R, L, T)                                                       \
-  while (iter < n_steady) {                                                            \
+#define COLATE_STEADY_B(R, L, T, P)                                                    \
+  while (iter < n_steady && last_pos) {                                                \
     if (tail_due(iter)) {                                                              \
-      iteration(R{}, L{}, C0{}, T{}, C1{});                                            \
-      if (++iter >= n_steady) break;                                                   \
+      iteration(R{}, L{}, C0{}, T{}, C1{}, P{});                                       \
+      if (++iter >= n_steady || !last_pos) break;                                      \
     }                                                                                  \
     int stop_ = tail_next_due(iter);                                                   \
     if (stop_ > n_steady) stop_ = n_steady;                                            \
-    while (__builtin_expect(iter < stop_, 1)) {                                        \
-      iteration(R{}, L{}, C0{}, T{}, C0{});                                            \
+    while (__builtin_expect(iter < stop_ && last_pos, 1)) {                            \
+      iteration(R{}, L{}, C0{}, T{}, C0{}, P{});                                       \
       ++iter;                                                                          \
     }                                                                                  \
   }
@@ -1322,26 +1375,26 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     // compiled the same way: runs on sparse tables go on for up to 1e5 iterations there (1.55 -> 1.31 us per iteration).
     // Only up to 64 epochs: with two epochs per lane the extra loops cost the steady ones 2.5 % (1.53 -> 1.57 ms at
     // E = 122, every code placement; profiles/r02_placement.txt) -- there the general loop takes over at min_iter.
-#define COLATE_STEADY_LL(R, L, T)                             \
-  for (; iter < max_iter; iter++) {                           \
-    if (iteration(R{}, L{}, C1{}, T{}, C0{})) {               \
+#define COLATE_STEADY_LL(R, L, T, P)                          \
+  for (; iter < max_iter && last_pos; iter++) {               \
+    if (iteration(R{}, L{}, C1{}, T{}, C0{}, P{})) {          \
       stopped = true;                                         \
       break;                                                  \
     }                                                         \
   }
-#define COLATE_STEADY_LL_B(R, L, T)                                                    \
-  while (iter < max_iter && !stopped) {                                                \
+#define COLATE_STEADY_LL_B(R, L, T, P)                                                 \
+  while (iter < max_iter && !stopped && last_pos) {                                    \
     if (tail_due(iter)) {                                                              \
-      if (iteration(R{}, L{}, C1{}, T{}, C1{})) {                                      \
+      if (iteration(R{}, L{}, C1{}, T{}, C1{}, P{})) {                                 \
         stopped = true;                                                                \
         break;                                                                         \
       }                                                                                \
-      if (++iter >= max_iter) break;                                                   \
+      if (++iter >= max_iter || !last_pos) break;                                      \
     }                                                                                  \
     int stop_ = tail_next_due(iter);                                                   \
     if (stop_ > max_iter) stop_ = max_iter;                                            \
-    for (; iter < stop_; iter++) {                                                     \
-      if (iteration(R{}, L{}, C1{}, T{}, C0{})) {                                      \
+    for (; iter < stop_ && last_pos; iter++) {                                         \
+      if (iteration(R{}, L{}, C1{}, T{}, C0{}, P{})) {                                 \
         stopped = true;                                                                \
         break;                                                                         \
       }                                                                                \
@@ -1351,24 +1404,24 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
 #define COLATE_LL_MAX_NCH 1  // (epochs per lane up to which the log-likelihood-phase loops are compiled, see below)
 #endif
 #ifdef COLATE_NO_LL_LOOPS  // (A/B switch: the iterations from min_iter on in the general loop)
-#define COLATE_BOTH(R, L, T)                                  \
+#define COLATE_BOTH(R, L, T, P)                               \
   {                                                           \
-    if (iter < n_steady) COLATE_STEADY(R, L, T);              \
+    if (iter < n_steady && last_pos) COLATE_STEADY(R, L, T, P); \
   }
-#define COLATE_BOTH_B(R, L, T)                                \
+#define COLATE_BOTH_B(R, L, T, P)                             \
   {                                                           \
-    COLATE_STEADY_B(R, L, T)                                  \
+    COLATE_STEADY_B(R, L, T, P)                               \
   }
 #else
-#define COLATE_BOTH(R, L, T)                                  \
+#define COLATE_BOTH(R, L, T, P)                               \
   {                                                           \
-    if (iter < n_steady) COLATE_STEADY(R, L, T);              \
-    if constexpr (NCH <= COLATE_LL_MAX_NCH) COLATE_STEADY_LL(R, L, T) \
+    if (iter < n_steady && last_pos) COLATE_STEADY(R, L, T, P); \
+    if constexpr (NCH <= COLATE_LL_MAX_NCH) COLATE_STEADY_LL(R, L, T, P) \
   }
-#define COLATE_BOTH_B(R, L, T)                                \
+#define COLATE_BOTH_B(R, L, T, P)                             \
   {                                                           \
-    COLATE_STEADY_B(R, L, T)                                  \
-    if constexpr (NCH <= COLATE_LL_MAX_NCH) COLATE_STEADY_LL_B(R, L, T) \
+    COLATE_STEADY_B(R, L, T, P)                               \
+    if constexpr (NCH <= COLATE_LL_MAX_NCH) COLATE_STEADY_LL_B(R, L, T, P) \
   }
 #endif
     using C2 = std::integral_constant<int, 2>;
@@ -1379,42 +1432,67 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     // (exp, the N and D terms, the stores) for its own slot: per wave about what 64 epochs cost.
     // any_more_rows / third_row are functions of the epochs' bin spans only, the same in every wave, so all four choose alike.
     const bool split = (NCH == 2) && !TPUT && NB >= 2;
+    // (last argument: the epoch values the wave computes in P1 -- 1 role A's, 2 role B's)
     if (!(any_more_rows || third_row)) {
-      if (role == 0) {  // (the wave that keeps the verdict's history is of role 0: wave 0 or wave 2)
+      if constexpr (kFree) {  // every wave of role A computes role A's epoch values, wave p1b_wave role B's
+        if (role == 0) {
+          if (leader) {
+            if (tracker) {
+              COLATE_BOTH(C0, C1, C1, C1)
+            } else {
+              COLATE_BOTH(C0, C1, C0, C1)
+            }
+          } else if (tracker) {
+            COLATE_BOTH(C0, C0, C1, C1)
+          } else {
+            COLATE_BOTH(C0, C0, C0, C1)
+          }
+        } else if (leader) {
+          if (wave == p1b_wave) {
+            COLATE_BOTH_B(C1, C1, C0, C2)
+          } else {
+            COLATE_BOTH_B(C1, C1, C0, C0)
+          }
+        } else if (wave == p1b_wave) {
+          COLATE_BOTH(C1, C0, C0, C2)
+        } else {
+          COLATE_BOTH(C1, C0, C0, C0)
+        }
+      } else if (role == 0) {  // (the wave that keeps the verdict's history is of role 0: wave 0 or wave 2)
         if (split && grp <= 1) {
           if constexpr (NCH == 2) {
             if (grp == 0) {
-              COLATE_BOTH(C0, C2, C1)  // (wave 0: keeps the verdict's history in the split)
+              COLATE_BOTH(C0, C2, C1, C1)  // (wave 0: keeps the verdict's history in the split)
             } else {
-              COLATE_BOTH(C0, C3, C0)
+              COLATE_BOTH(C0, C3, C0, C1)
             }
           }
         } else if (leader) {
           if (tracker) {
-            COLATE_BOTH(C0, C1, C1)
+            COLATE_BOTH(C0, C1, C1, C1)
           } else {
-            COLATE_BOTH(C0, C1, C0)
+            COLATE_BOTH(C0, C1, C0, C1)
           }
         } else {
           if (tracker) {
-            COLATE_BOTH(C0, C0, C1)
+            COLATE_BOTH(C0, C0, C1, C0)
           } else {
-            COLATE_BOTH(C0, C0, C0)
+            COLATE_BOTH(C0, C0, C0, C0)
           }
         }
       } else {
         if (split && grp <= 1) {
           if constexpr (NCH == 2) {
             if (grp == 0) {
-              COLATE_BOTH_B(C1, C2, C0)
+              COLATE_BOTH_B(C1, C2, C0, C2)
             } else {
-              COLATE_BOTH_B(C1, C3, C0)
+              COLATE_BOTH_B(C1, C3, C0, C2)
             }
           }
         } else if (leader) {
-          COLATE_BOTH_B(C1, C1, C0)
+          COLATE_BOTH_B(C1, C1, C0, C2)
         } else {
-          COLATE_BOTH(C1, C0, C0)
+          COLATE_BOTH(C1, C0, C0, C0)
         }
       }
     }
@@ -1428,7 +1506,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     // needed" only: no cost for the steady loops, 2.20 -> 2.08 us per iteration at E = 122
     if constexpr (NCH > COLATE_LL_MAX_NCH) if (!(any_more_rows || third_row)) {
       for (; iter < max_iter; iter++) {
-        if (iteration(CR{}, CR{}, C1{}, CR{}, CR{})) {
+        if (iteration(CR{}, CR{}, C1{}, CR{}, CR{}, CR{})) {
           stopped = true;
           break;
         }
@@ -1437,7 +1515,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   }
   for (; !stopped && iter < max_iter; iter++) {
     using CRt = std::integral_constant<int, -1>;
-    if (iteration(CRt{}, CRt{}, CRt{}, CRt{}, CRt{})) break;
+    if (iteration(CRt{}, CRt{}, CRt{}, CRt{}, CRt{}, CRt{})) break;
   }
 
 #ifdef COLATE_EM_STAMPS
@@ -1559,7 +1637,7 @@ inline size_t em_lds_bytes(int E, int A, bool tput) {
   const size_t EPAD = (size_t)em_chunks(E) * kWave;
   const size_t AP = (size_t)em_groups(A) * kWave;
   const size_t APZ = AP + 2;
-  const size_t doubles = (EPAD + 1) + num_gather_rows(em_chunks(E)) * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ + 12 +
+  const size_t doubles = (EPAD + 1) + num_gather_rows(em_chunks(E), tput) * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ + 12 +
                          em::kExpTableDoubles + AP + tail_scratch_arrays(em_chunks(E), tput) * APZ;
   const size_t ints = (AP + 1) + 8 + 4 + AP;
   return doubles * sizeof(double) + ints * sizeof(int);

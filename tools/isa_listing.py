@@ -69,11 +69,15 @@ def cls(op, args):
     return "other"
 
 
-kinds = {"C0, C2, C1": "role A (shared), split: even epochs, keeps the verdict history (wave 0)", "C1, C2, C0": "role B (not shared), split: even epochs (wave 1)",
-         "C0, C3, C0": "role A, split: odd epochs (wave 2)", "C1, C3, C0": "role B, split: odd epochs (wave 3)",
-         "C0, C1, C0": "role A (shared) leader", "C1, C1, C0": "role B (not shared) leader",
-         "C0, C0, C1": "role A second bin group, keeps the verdict history", "C1, C0, C0": "role B second bin group",
-         "C0, C1, C1": "role A leader that also keeps the verdict history (one bin group only)", "C0, C0, C0": "role A further bin groups"}
+kinds = {"C0, C2, C1, C1": "role A (shared), split: even epochs, keeps the verdict history (wave 0)", "C1, C2, C0, C2": "role B (not shared), split: even epochs (wave 1)",
+         "C0, C3, C0, C1": "role A, split: odd epochs (wave 2)", "C1, C3, C0, C2": "role B, split: odd epochs (wave 3)",
+         "C0, C1, C0, C1": "role A (shared) leader (wave 0)", "C1, C1, C0, C0": "role B (not shared) leader whose epoch values wave 3 computes (wave 1)",
+         "C0, C0, C1, C1": "role A second bin group, computes role A's epoch values for itself, keeps the verdict history (wave 2)",
+         "C1, C0, C0, C2": "role B second bin group, computes role B's epoch values (wave 3)",
+         "C1, C1, C0, C2": "role B (not shared) leader that computes its epoch values",
+         "C0, C1, C1, C1": "role A leader that also keeps the verdict history (one bin group only)",
+         "C0, C0, C0, C1": "role A further bin groups (compute role A's epoch values for themselves)", "C1, C0, C0, C0": "role B further bin groups",
+         "C0, C0, C1, C0": "role A second bin group, keeps the verdict history", "C0, C0, C0, C0": "role A further bin groups"}
 print(f"# Steady-state EM loops of {pat} (gfx950), built as the Makefile builds em_kernels_ilp.hip")
 # every backward branch whose range holds exactly the three barriers of an iteration is a loop; the COLATE_BOTH(...) line
 # that some instruction of it (the iteration counter) is attributed to tells the kind of wave; of the two loops of a kind
@@ -86,15 +90,16 @@ for k, (a, op, args, line) in enumerate(ins):
     if t > a or t not in index:
         continue
     k0 = index[t]
-    if sum(1 for x in ins[k0:k] if x[1] == "s_barrier") != 3:
+    nbar = sum(1 for x in ins[k0:k] if x[1] == "s_barrier")
+    if nbar not in (2, 3):  # (2: one epoch per lane, latency variant -- no barrier between the epoch values and the bin terms)
         continue
     tags = {m.group(1) for x in ins[k0:k + 1] if x[3] for m in [re.search(r"COLATE_BOTH(?:_B)?\(([^)]*)\)", impl_lines[x[3] - 1])] if m}
     if len(tags) == 1:
-        found[tags.pop()].append((k - k0, k0, k))
+        found[tags.pop()].append((nbar, k - k0, k0, k))
 loops = []
 for tag, what in kinds.items():
     if found.get(tag):
-        _, k0, k1 = min(found[tag])
+        _, _, k0, k1 = min(found[tag])
         loops.append((tag, what, k0, k1))
 for tag, what, k0, k1 in loops:
     seg = ins[k0:k1 + 1]
@@ -106,7 +111,7 @@ names = ["P1 epoch values (leaders: cs scan + exp_om | exp, 1/lambda, beta) + ra
          "P2 bin terms + row-segmented reduce + tails  -> barrier 2",
          "P3 per-epoch sums, suffix scan | affine scan, partial N, D (leaders)  -> barrier 3",
          "P4 M-step  -> back edge"]
-for tag, what, k0, k1 in loops[:2]:  # the two leaders in full
+for tag, what, k0, k1 in loops[:int(os.environ.get("FULL", "4"))]:  # the first four kinds in full
     print(f"\n\n################ {what}  [COLATE_BOTH({tag})]")
     seg = ins[k0:k1 + 1]
     targets = {target(a, args) for a, op, args, _ in ins if op.startswith(("s_cbranch", "s_branch"))}
