@@ -224,10 +224,10 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput, int wpe) {
   // The pad shifts everything behind it, the loops compiled per kind of wave included.
 #ifdef COLATE_EM_ILP_BUILD
   (void)tput;
-  // latency variant, max-ilp build, kernel ms for pads 0..7 (gpurun_out/r03n, r03o -> profiles/r03_placement.txt):
-  // E=23 B=100 (the build without the register cap) 1.029 1.031 1.016 1.030 1.006 1.025 1.034 1.035;
-  // E=23 B=400 (with it) 1.237 1.238 1.238 1.254 1.247 1.255 1.247 1.243; E=122 B=100 1.363 1.372 1.361 1.379 1.368 1.367 1.371 1.344
-  return nch == 1 ? (wpe == 2 ? 4 : 2) : 7;
+  // latency variant, max-ilp build, kernel ms for pads 0..7 (gpurun_out/r03z/pads2_* -> profiles/r03_placement.txt):
+  // E=23 B=100 (the build without the register cap, no barrier 1) 1.022 0.982 0.989 1.014 1.037 0.988 1.038 1.024;
+  // E=23 B=400 (with the cap) 1.249 1.251 1.250 1.244 1.241 1.253 1.249 1.257; E=122 B=100 1.344 1.355 1.341 1.357 1.367 1.352 1.355 1.364
+  return nch == 1 ? (wpe == 2 ? 1 : 4) : 2;
 #else
   (void)nch;
   if (!tput) return 6;  // latency variant, default build (not picked by colate_em_variant any more; COLATE_EM_VARIANT=latency)
@@ -503,7 +503,10 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   // leaders it cost 3.5 % at E=23 and 7 % at E=122, profiles/r02_placement.txt), else wave 0.
   // (with two epochs per lane and two bin groups all four waves own epoch work -- the split below -- and wave 0 is the one with
   // slack: its slot's scans need no hand-over from the other owner)
-  const int verdict_wave = (!TPUT && NB >= 2 && NCH != 2) ? 2 : 0;
+  // (the free mode of the loop -- see kFree below -- loads role A's waves up to barrier 2 and leaves role B's leader, whose
+  // epoch values wave 3 computes, the most room: it keeps the history there)
+  constexpr bool kFreeBuild = !TPUT && NCH == 1 && WPE == 2;
+  const int verdict_wave = (!TPUT && NB >= 2 && NCH != 2) ? (kFreeBuild ? 1 : 2) : 0;
   const bool tracker = (wave == verdict_wave);
   constexpr int erows = EROWS;  // 16-lane rows that hold epochs: a compile-time constant (skipping the cross-row
                                 // scan steps behind run-time uniform branches measured slower)
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   // Measured on one box (gpurun_out/r03z -> profiles/r03_free_mode.txt): 0.990 against 1.000 ms at B = 100 -- and 1.279 against
   // 1.238 ms at B = 400, where two workgroups share a CU and the instructions of the redundant scans (+8 % in total) are no
   // longer free: the mode belongs to the build for batches that leave every workgroup a CU to itself (WPE == 2).
-  constexpr bool kFree = !TPUT && NCH == 1 && WPE == 2;
+  constexpr bool kFree = kFreeBuild;
   const int p1b_wave = (kFree && NB >= 2) ? 3 : 1;
   const int nwave_live = 2 * NB;
   (void)nwave_live;
@@ -580,7 +583,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   // free mode: the last rate is positive (after the latest M-step; the same in every wave) -- what the loops compiled per kind of
   // wave assume; always true otherwise (those loops test it themselves where it matters)
   bool last_pos = true;
-  if (kFree) last_pos = (ballot64(lam_e[0] > 0.0) >> (E - 1)) & 1ull;
+  const unsigned long long last_bit = 1ull << ((E - 1) & 63);  // (free mode has one epoch per lane: the last epoch's lane)
+  if (kFree) last_pos = (ballot64(lam_e[0] > 0.0) & last_bit) != 0ull;
   auto tail_due = [&](int it) { return (it & (it - 1)) == 0; };
   auto tail_next_due = [&](int it) { return it <= 1 ? it : (1 << (32 - __builtin_clz((unsigned)(it - 1)))); };  // first due iteration >= it
   auto iteration = [&](auto role_c, auto leader_c, auto ll_c, auto track_c, auto refresh_c, auto p1_c) __attribute__((always_inline)) -> bool {
@@ -1324,7 +1328,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
         }
       }
     }
-    if (kFree && kSteady) last_pos = (ballot64(lam_e[0] > 0.0) >> (E - 1)) & 1ull;  // (for the loop conditions: see `kFree`)
+    // (for the loop conditions, see `kFree`; as scalar arithmetic on the compare's lane mask -- written as a shift of the mask the
+    // compiler made a per-lane value and an exec-masked loop of it: 14 instructions at the top of every iteration)
+    if (kFree && kSteady) last_pos = (ballot64(lam_e[0] > 0.0) & last_bit) != 0ull;
     COLATE_STAMP(5)
     // stop rule, coal.cpp:3822 (evaluated after the update); uniform across the workgroup
     bool stop = false;
@@ -1442,8 +1448,6 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
             } else {
               COLATE_BOTH(C0, C1, C0, C1)
             }
-          } else if (tracker) {
-            COLATE_BOTH(C0, C0, C1, C1)
           } else {
             COLATE_BOTH(C0, C0, C0, C1)
           }
@@ -1451,7 +1455,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
           if (wave == p1b_wave) {
             COLATE_BOTH_B(C1, C1, C0, C2)
           } else {
-            COLATE_BOTH_B(C1, C1, C0, C0)
+            COLATE_BOTH_B(C1, C1, C1, C0)  // (two or more bin groups: keeps the verdict's history)
           }
         } else if (wave == p1b_wave) {
           COLATE_BOTH(C1, C0, C0, C2)

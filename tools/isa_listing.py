@@ -5,6 +5,10 @@ the s_barrier instructions, with instruction-class counts per phase and every br
 committed as profiles/r02_isa_loop_<name>.txt.
 
     python tools/isa_listing.py 'em_kernelILi0ELi1ELi2ELb0' > profiles/r02_isa_loop_e23_latency_ilp.txt
+    EXTRA_FLAGS=-DCOLATE_NO_LL_LOOPS python tools/isa_listing.py 'em_kernelILi0ELi1ELi2ELb0ELi2E' > profiles/r03_isa_loop_e23_latency_ilp.txt
+(round 3: the build for batches that leave every workgroup a CU has two barriers per steady-state iteration and three in the
+loops of the log-likelihood phase, whose out-of-line blocks confuse the "shorter of two loops" rule below: list it with the
+log-likelihood loops compiled out -- same steady-state loops, other addresses)
 
 Builds colate_amd/csrc/em_kernels_ilp.hip with the Makefile's flags (+ line tables) to a device ELF and disassembles it
 (llvm-objdump -l).  A loop is a backward branch over exactly three barriers; the COLATE_BOTH(...) line its iteration counter
@@ -71,12 +75,11 @@ def cls(op, args):
 
 kinds = {"C0, C2, C1, C1": "role A (shared), split: even epochs, keeps the verdict history (wave 0)", "C1, C2, C0, C2": "role B (not shared), split: even epochs (wave 1)",
          "C0, C3, C0, C1": "role A, split: odd epochs (wave 2)", "C1, C3, C0, C2": "role B, split: odd epochs (wave 3)",
-         "C0, C1, C0, C1": "role A (shared) leader (wave 0)", "C1, C1, C0, C0": "role B (not shared) leader whose epoch values wave 3 computes (wave 1)",
-         "C0, C0, C1, C1": "role A second bin group, computes role A's epoch values for itself, keeps the verdict history (wave 2)",
+         "C0, C1, C0, C1": "role A (shared) leader (wave 0)", "C1, C1, C1, C0": "role B (not shared) leader whose epoch values wave 3 computes, keeps the verdict history (wave 1)",
          "C1, C0, C0, C2": "role B second bin group, computes role B's epoch values (wave 3)",
          "C1, C1, C0, C2": "role B (not shared) leader that computes its epoch values",
          "C0, C1, C1, C1": "role A leader that also keeps the verdict history (one bin group only)",
-         "C0, C0, C0, C1": "role A further bin groups (compute role A's epoch values for themselves)", "C1, C0, C0, C0": "role B further bin groups",
+         "C0, C0, C0, C1": "role A second and further bin groups, compute role A's epoch values for themselves (wave 2)", "C1, C0, C0, C0": "role B further bin groups",
          "C0, C0, C1, C0": "role A second bin group, keeps the verdict history", "C0, C0, C0, C0": "role A further bin groups"}
 print(f"# Steady-state EM loops of {pat} (gfx950), built as the Makefile builds em_kernels_ilp.hip")
 # every backward branch whose range holds exactly the three barriers of an iteration is a loop; the COLATE_BOTH(...) line
