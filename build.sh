@@ -9,7 +9,7 @@ make -C colate_amd/csrc
   /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 \
     -I../../include -I. -Wno-unused-value tools/residency_probe.hip -o ../bin/residency_probe
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-unused-value tools/fetch_calib.hip -o ../bin/fetch_calib
-  for u in ubench ubench_branch ubench_ldsatomic ubench_mfma ubench_exec ubench_fetch; do
+  for u in ubench ubench_branch ubench_ldsatomic ubench_mfma ubench_exec ubench_clock ubench_fetch ubench_fetch2 ubench_fetch3; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-value tools/$u.hip -o ../bin/$u
   done )
 make -C oracle oracle

@@ -5,7 +5,7 @@ the s_barrier instructions, with instruction-class counts per phase and every br
 committed as profiles/r02_isa_loop_<name>.txt.
 
     python tools/isa_listing.py 'em_kernelILi0ELi1ELi2ELb0' > profiles/r02_isa_loop_e23_latency_ilp.txt
-    EXTRA_FLAGS=-DCOLATE_NO_LL_LOOPS python tools/isa_listing.py 'em_kernelILi0ELi1ELi2ELb0ELi2E' > profiles/r03_isa_loop_e23_latency_ilp.txt
+    NBAR=2 EXTRA_FLAGS=-DCOLATE_NO_LL_LOOPS python tools/isa_listing.py 'em_kernelILi0ELi1ELi2ELb0ELi2E' > profiles/r03_isa_loop_e23_latency_ilp.txt
 (round 3: the build for batches that leave every workgroup a CU has two barriers per steady-state iteration and three in the
 loops of the log-likelihood phase, whose out-of-line blocks confuse the "shorter of two loops" rule below: list it with the
 log-likelihood loops compiled out -- same steady-state loops, other addresses)
@@ -94,7 +94,7 @@ for k, (a, op, args, line) in enumerate(ins):
         continue
     k0 = index[t]
     nbar = sum(1 for x in ins[k0:k] if x[1] == "s_barrier")
-    if nbar not in (2, 3):  # (2: one epoch per lane, latency variant -- no barrier between the epoch values and the bin terms)
+    if nbar != int(os.environ.get("NBAR", "3")):  # (NBAR=2: the build for B <= #CUs at up to 64 epochs has no barrier between the epoch values and the bin terms)
         continue
     tags = {m.group(1) for x in ins[k0:k + 1] if x[3] for m in [re.search(r"COLATE_BOTH(?:_B)?\(([^)]*)\)", impl_lines[x[3] - 1])] if m}
     if len(tags) == 1:
@@ -114,6 +114,8 @@ names = ["P1 epoch values (leaders: cs scan + exp_om | exp, 1/lambda, beta) + ra
          "P2 bin terms + row-segmented reduce + tails  -> barrier 2",
          "P3 per-epoch sums, suffix scan | affine scan, partial N, D (leaders)  -> barrier 3",
          "P4 M-step  -> back edge"]
+if os.environ.get("NBAR", "3") == "2":
+    names = ["P1 + P2: epoch values (every role-A wave for itself; wave 3 role B's), rate / S_k fetch by ds_bpermute, bin terms + row-segmented reduce + tails -- no barrier between  -> barrier 2"] + names[2:]
 for tag, what, k0, k1 in loops[:int(os.environ.get("FULL", "4"))]:  # the first four kinds in full
     print(f"\n\n################ {what}  [COLATE_BOTH({tag})]")
     seg = ins[k0:k1 + 1]
