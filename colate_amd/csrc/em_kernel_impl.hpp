@@ -94,6 +94,8 @@ __device__ __forceinline__ double wave_prefix_sum(double v, int rows = 4) {
   v += dpp_d<ROW_SHR2, 0xf, true>(0.0, v);
   v += dpp_d<ROW_SHR4, 0xf, true>(0.0, v);
   v += dpp_d<ROW_SHR8, 0xf, true>(0.0, v);
+  // (row_bcast15 leaves the lanes of row 0 unwritten even with bound_ctrl -- tried with row_mask 0xf to save the two v_mov that
+  // set up `old`: row 0 then keeps whatever the register held, and test_l2_golden failed; the masked form it is)
   if (rows > 1) v += dpp_d<ROW_BCAST15, 0xa>(0.0, v);
   if (rows > 2) v += dpp_d<ROW_BCAST31, 0xc>(0.0, v);
   return v;
@@ -121,21 +123,36 @@ __device__ __forceinline__ double wave_suffix_sum(double v, int lane, int rows =
 }
 // inclusive prefix composition of the affine maps x -> a*x + b (lane order = application order):
 // afterwards (a, b) of lane l is f_l o ... o f_0
-__device__ __forceinline__ void wave_affine_scan(double& a, double& b, int rows = 4) {
-#define COLATE_AFF_STEP(CTRL, RM, BND)             \
+// (`nosrc`: null, or four per-lane constants -- 1.0 where the lane has no source 1 / 2 / 4 / 8 lanes to its left in its row, else 0.0.
+// A lane without a source must see the identity map: its multiplier reads 1.  As `old` of the DPP move that is two v_mov per
+// step -- the compiler sets the register pair up again every time --; as zero fill plus the constant it is one addition.)
+__device__ __forceinline__ void wave_affine_scan(double& a, double& b, int rows = 4, const double* nosrc = nullptr) {
+#define COLATE_AFF_STEP(CTRL, RM, BND, K)                                                                   \
+  {                                                                                                         \
+    const double as = nosrc ? dpp_d<CTRL, RM, true>(0.0, a) + nosrc[K] : dpp_d<CTRL, RM>(1.0, a);           \
+    const double bs = dpp_d<CTRL, RM, BND>(0.0, b);                                                         \
+    b = em::fma_(a, bs, b);                                                                                 \
+    a = a * as;                                                                                             \
+  }
+  COLATE_AFF_STEP(ROW_SHR1, 0xf, true, 0)
+  COLATE_AFF_STEP(ROW_SHR2, 0xf, true, 1)
+  COLATE_AFF_STEP(ROW_SHR4, 0xf, true, 2)
+  COLATE_AFF_STEP(ROW_SHR8, 0xf, true, 3)
+#undef COLATE_AFF_STEP
+  if (rows == 2) {  // (the last step: only b is used afterwards)
+    const double bs = dpp_d<ROW_BCAST15, 0xa>(0.0, b);
+    b = em::fma_(a, bs, b);
+  }
+#define COLATE_AFF_STEP2(CTRL, RM)                 \
   {                                                \
     const double as = dpp_d<CTRL, RM>(1.0, a);     \
-    const double bs = dpp_d<CTRL, RM, BND>(0.0, b); \
+    const double bs = dpp_d<CTRL, RM>(0.0, b);     \
     b = em::fma_(a, bs, b);                        \
     a = a * as;                                    \
   }
-  COLATE_AFF_STEP(ROW_SHR1, 0xf, true)
-  COLATE_AFF_STEP(ROW_SHR2, 0xf, true)
-  COLATE_AFF_STEP(ROW_SHR4, 0xf, true)
-  COLATE_AFF_STEP(ROW_SHR8, 0xf, true)
-  if (rows > 1) COLATE_AFF_STEP(ROW_BCAST15, 0xa, false)
-  if (rows > 2) COLATE_AFF_STEP(ROW_BCAST31, 0xc, false)
-#undef COLATE_AFF_STEP
+  if (rows > 2) COLATE_AFF_STEP2(ROW_BCAST15, 0xa)
+  if (rows > 2) COLATE_AFF_STEP2(ROW_BCAST31, 0xc)
+#undef COLATE_AFF_STEP2
 }
 
 // inclusive suffix maximum of non-negative values (lane l: max of lanes l..63)
@@ -224,14 +241,14 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput, int wpe) {
   // The pad shifts everything behind it, the loops compiled per kind of wave included.
 #ifdef COLATE_EM_ILP_BUILD
   (void)tput;
-  // latency variant, max-ilp build, kernel ms for pads 0..7 (gpurun_out/r03z/pads2_* -> profiles/r03_placement.txt):
-  // E=23 B=100 (the build without the register cap, no barrier 1) 1.022 0.982 0.989 1.014 1.037 0.988 1.038 1.024;
-  // E=23 B=400 (with the cap) 1.249 1.251 1.250 1.244 1.241 1.253 1.249 1.257; E=122 B=100 1.344 1.355 1.341 1.357 1.367 1.352 1.355 1.364
-  return nch == 1 ? (wpe == 2 ? 1 : 4) : 2;
+  // latency variant, max-ilp build, kernel ms for pads 0..7 (gpurun_out/r03z/pads5_* -> profiles/r03_placement.txt; final code of round 3):
+  // E=23 B=100 (the build without the register cap, two barriers) 0.936 0.942 0.993 0.977 0.957 0.967 0.944 0.942;
+  // E=23 B=400 (with the cap) 1.230 1.216 1.212 1.226 1.229 1.216 1.215 1.221; E=122 B=100 1.350 1.330 1.341 1.337 1.339 1.320 1.325 1.345
+  return nch == 1 ? (wpe == 2 ? 0 : 2) : 5;
 #else
   (void)nch;
   if (!tput) return 6;  // latency variant, default build (not picked by colate_em_variant any more; COLATE_EM_VARIANT=latency)
-  return 0;             // throughput variant: E=23 B=4096 6.605 6.625 6.657 6.637 6.694 6.678 6.623 6.681
+  return 3;             // throughput variant: E=23 B=4096 6.478 6.487 6.511 6.423 6.467 6.451 6.567 6.549 (round 3, final code)
 #endif
 #endif
 }
@@ -528,6 +545,14 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   // 1.238 ms at B = 400, where two workgroups share a CU and the instructions of the redundant scans (+8 % in total) are no
   // longer free: the mode belongs to the build for batches that leave every workgroup a CU to itself (WPE == 2).
   constexpr bool kFree = kFreeBuild;
+  // (this build has registers to spare: the affine scan's "no source lane" constants, see wave_affine_scan)
+  double aff_nosrc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (kFree) {
+    aff_nosrc[0] = (lane & 15) < 1 ? 1.0 : 0.0;
+    aff_nosrc[1] = (lane & 15) < 2 ? 1.0 : 0.0;
+    aff_nosrc[2] = (lane & 15) < 4 ? 1.0 : 0.0;
+    aff_nosrc[3] = (lane & 15) < 8 ? 1.0 : 0.0;
+  }
   const int p1b_wave = (kFree && NB >= 2) ? 3 : 1;
   const int nwave_live = 2 * NB;
   (void)nwave_live;
@@ -583,6 +608,10 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   // free mode: the last rate is positive (after the latest M-step; the same in every wave) -- what the loops compiled per kind of
   // wave assume; always true otherwise (those loops test it themselves where it matters)
   bool last_pos = true;
+  // ... and how the loops learn of it: `lim` is the iteration bound of whichever per-kind loop is running, and the M-step sets it to 0
+  // when the last rate is not positive -- one s_cselect in the iteration and a plain counted loop around it (as a second loop
+  // condition it cost every wave twelve scalar instructions and two branches per iteration)
+  int lim = 0;
   const unsigned long long last_bit = 1ull << ((E - 1) & 63);  // (free mode has one epoch per lane: the last epoch's lane)
   if (kFree) last_pos = (ballot64(lam_e[0] > 0.0) & last_bit) != 0ull;
   auto tail_due = [&](int it) { return (it & (it - 1)) == 0; };
@@ -751,7 +780,48 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
       const int wslot = 2 * (pos >> 6) + ROLE;  // entry of this (bin group, ROLE) in s_fail / s_ll: the latency variant's wave
       double o_w = 0, o_N = 0, o_D = 0, llp = 0.0;
       bool fail = false;
-      if (live && !COLATE_ABL_HAS(12)) {
+      if (ROLE == 0 && !COLATE_ABL_HAS(12)) {
+        // ---- EM_shared, coal_EM.cpp:198-210, 263-287, WITHOUT exec-masked branches on `live` and `finite_pos(Sig)`: every lane
+        // computes, the three results are selected at the end.  The two branches cost the wave 14 scalar / branch instructions per
+        // iteration -- each an issue slot like an FP64 instruction -- against 6 v_cndmask here; a lane without data computes on
+        // zeros (its gathers read epoch E's column, inside the rows) and is dropped.
+        const double lk = have_lk ? lk_own : s_ep[G_LAM * EPAD + kb];
+        // 1 / lambda_k: the per-epoch value of P1, or the bin's own division (the same operation on the same operand)
+        const double ik = cross ? 1.0 / lk : s_ep[G_INV * EPAD + kb];
+        const bool lpos = lk > 0;
+        const double Sk = cross ? Sk_in : s_ep[G_S * EPAD + kb], PWk = cross ? PWk_in : s_ep[G_PW * EPAD + kb];
+        const double Xak = cross ? em::em_div_known_rcp(tk + ik, ik, lk) : s_ep[G_XA * EPAD + kb];  // (t_k + 1/lambda)/(1/lambda), coal_EM.cpp:204
+#if COLATE_ABL_HAS(5)
+        const double qd = 1.0 - lk * da;
+#else
+        const double qd = cross ? qd_in : em::em_exp_t(-(lk * da), s_exptab);  // exp(-cumsum(age) + cumsum(t_k)): same up to the rounding of cumsum
+#endif
+#if COLATE_ABL_HAS(8)
+        const double Y = (a_b + ik) * lk;
+#else
+        const double Y = em::em_div_known_rcp(a_b + ik, ik, lk);  // (age + 1/lambda)/(1/lambda), coal_EM.cpp:204
+#endif
+        const double Wp = lpos ? Sk * (1.0 - qd) : 0.0;
+        const double X = Xak - Y * qd;
+        const double Vp = lpos ? X * ik * Sk : 0.0;
+        const double Sig = PWk + Wp;
+        const bool fin = finite_pos(Sig), ok = live && fin;
+        const double r = em::em_rcp(Sig);
+        const double nk = Wp * r;
+        double dk = Vp * r + (-tk * nk);
+        dk = __builtin_fmax(dk, 0.0);
+        o_w = ok ? cnt * r : 0.0;
+        o_N = ok ? cnt * nk : 0.0;
+        o_D = ok ? cnt * dk : 0.0;
+        fail = live && !fin;
+        if (need_ll) {
+          COLATE_COLD();
+          llp = ok ? cnt * em::em_log(Sig) : 0.0;
+        }
+      } else if (ROLE == 1 && !COLATE_ABL_HAS(12)) {
+        // ---- EM_notshared, coal_EM.cpp:330-357, 435-460, likewise without a branch on `live`: a lane without data has a count of
+        // (+)0 and finite factors -- every static of a lane beyond the data is 0, exp never returns a NaN, and the selects on
+        // `lambda_k > 0` keep 1 / lambda_k = inf out -- so its three products are the +0.0 the branch used to leave there.
         const double lk = have_lk ? lk_own : s_ep[G_LAM * EPAD + kb];
         // 1 / lambda_k: the per-epoch value of P1, or the bin's own division (the same operation on the same operand)
         const double ik = cross ? 1.0 / lk : s_ep[G_INV * EPAD + kb];
@@ -762,91 +832,57 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
           const double ck1 = ck + lk * da;
           return -(ck1 + lk * (a_b - a_b));  // (second copy of `age` in the merged grid)
         };
-        if (ROLE == 0) {  // ---- EM_shared, coal_EM.cpp:198-210, 263-287
-          const double Sk = cross ? Sk_in : s_ep[G_S * EPAD + kb], PWk = cross ? PWk_in : s_ep[G_PW * EPAD + kb];
-          const double Xak = cross ? em::em_div_known_rcp(tk + ik, ik, lk) : s_ep[G_XA * EPAD + kb];  // (t_k + 1/lambda)/(1/lambda), coal_EM.cpp:204
-#if COLATE_ABL_HAS(5)
-          const double qd = 1.0 - lk * da;
-#else
-          const double qd = cross ? qd_in : em::em_exp_t(-(lk * da), s_exptab);  // exp(-cumsum(age) + cumsum(t_k)): same up to the rounding of cumsum
-#endif
-#if COLATE_ABL_HAS(8)
-          const double Y = (a_b + ik) * lk;
-#else
-          const double Y = em::em_div_known_rcp(a_b + ik, ik, lk);  // (age + 1/lambda)/(1/lambda), coal_EM.cpp:204
-#endif
-          const double Wp = lpos ? Sk * (1.0 - qd) : 0.0;
-          const double X = Xak - Y * qd;
-          const double Vp = lpos ? X * ik * Sk : 0.0;
-          const double Sig = PWk + Wp;
-          if (finite_pos(Sig)) {
-            const double r = em::em_rcp(Sig);
-            const double nk = Wp * r;
-            double dk = Vp * r + (-tk * nk);
-            dk = __builtin_fmax(dk, 0.0);
-            o_w = cnt * r;
-            o_N = cnt * nk;
-            o_D = cnt * dk;
-            if (need_ll) {
-              COLATE_COLD();
-              llp = cnt * em::em_log(Sig);
-            }
-          } else {
-            fail = true;
-          }
-        } else {  // ---- EM_notshared, coal_EM.cpp:330-357, 435-460
-          // every live lane takes the general path (db = 0 in the last epoch, so it is harmless there); the few bins
-          // beyond the start of the last epoch are put right afterwards, behind a wave-uniform test
-          {
+        // every lane takes the general path (db = 0 in the last epoch, so it is harmless there); the few bins
+        // beyond the start of the last epoch are put right afterwards, behind a wave-uniform test
 #if COLATE_ABL_HAS(6)
-            const double u = 1.0 - lk * db;
+        const double u = 1.0 - lk * db;
 #else
-            const double u = em::em_exp_t(-(lk * db), s_exptab);  // exp(-cumsum(t_{k+1}) + cumsum(age)), likewise
+        const double u = em::em_exp_t(-(lk * db), s_exptab);  // exp(-cumsum(t_{k+1}) + cumsum(age)), likewise
 #endif
-            const double pn = lpos ? 1.0 - u : 0.0;
-            const double bn = lpos ? (a_b + ik) - (tkn + ik) * u : 0.0;
-            {  // the last epoch absorbs: normaliser = exp(-cs(age)) * ((1 - u) + u) = exp(-cs(age))
-              double dk = bn + (-tk * pn + dtk * (1.0 - pn));
+        const double pn = lpos ? 1.0 - u : 0.0;
+        const double bn = lpos ? (a_b + ik) - (tkn + ik) * u : 0.0;
+        {  // the last epoch absorbs: normaliser = exp(-cs(age)) * ((1 - u) + u) = exp(-cs(age))
+          double dk = bn + (-tk * pn + dtk * (1.0 - pn));
+          dk = __builtin_fmax(dk, 0.0);
+          o_w = cnt * u;
+          o_N = cnt * pn;
+          o_D = cnt * dk;
+          if (need_ll) {
+            COLATE_COLD();
+            llp = live ? cnt * neg_cs_age() : 0.0;
+          }
+        }
+        if (__builtin_expect(!absorbing, 0)) {  // last rate is 0: the mass beyond t_{k+1} is 1 - S_{E-1}/S_{k+1}
+          COLATE_COLD();
+          o_w = o_N = o_D = llp = 0.0;
+          if (live) {
+            const double Gk1 = 1.0 - em::em_exp_t(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + kb + 1], s_exptab);
+            const double SigN = pn + u * Gk1;
+            if (finite_pos(SigN)) {
+              const double rr = 1.0 / SigN;
+              const double nk = pn * rr;
+              double dk = bn * rr + (-tk * nk + dtk * (1.0 - nk));
               dk = __builtin_fmax(dk, 0.0);
-              o_w = cnt * u;
-              o_N = cnt * pn;
+              o_w = cnt * (u * rr);
+              o_N = cnt * nk;
               o_D = cnt * dk;
-              if (need_ll) {
-                COLATE_COLD();
-                llp = cnt * neg_cs_age();
-              }
-            }
-            if (__builtin_expect(!absorbing, 0)) {  // last rate is 0: the mass beyond t_{k+1} is 1 - S_{E-1}/S_{k+1}
-              COLATE_COLD();
-              const double Gk1 = 1.0 - em::em_exp_t(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + kb + 1], s_exptab);
-              const double SigN = pn + u * Gk1;
-              o_w = o_N = o_D = llp = 0.0;
-              if (finite_pos(SigN)) {
-                const double rr = 1.0 / SigN;
-                const double nk = pn * rr;
-                double dk = bn * rr + (-tk * nk + dtk * (1.0 - nk));
-                dk = __builtin_fmax(dk, 0.0);
-                o_w = cnt * (u * rr);
-                o_N = cnt * nk;
-                o_D = cnt * dk;
-                llp = cnt * (neg_cs_age() + em::em_log(SigN));
-              } else {
-                fail = true;
-              }
+              llp = cnt * (neg_cs_age() + em::em_log(SigN));
+            } else {
+              fail = true;
             }
           }
-          if (__builtin_expect(ballot64(last_bin) != 0, 0)) {
-            COLATE_COLD();
-            if (last_bin) {  // bin beyond the start of the last epoch, coal_EM.cpp:350-357
-              if (!lpos) my_flags |= COLATE_FLAG_NAN;  // reference: assert(coal_rate_e > 0)
-              double dk = (a_b + ik) - tk;
-              dk = __builtin_fmax(dk, 0.0);
-              o_w = 0.0;
-              o_N = cnt;
-              o_D = cnt * dk;
-              fail = false;
-              llp = need_ll ? cnt * neg_cs_age() : 0.0;
-            }
+        }
+        if (__builtin_expect(ballot64(last_bin && live) != 0, 0)) {
+          COLATE_COLD();
+          if (last_bin && live) {  // bin beyond the start of the last epoch, coal_EM.cpp:350-357
+            if (!lpos) my_flags |= COLATE_FLAG_NAN;  // reference: assert(coal_rate_e > 0)
+            double dk = (a_b + ik) - tk;
+            dk = __builtin_fmax(dk, 0.0);
+            o_w = 0.0;
+            o_N = cnt;
+            o_D = cnt * dk;
+            fail = false;
+            llp = need_ll ? cnt * neg_cs_age() : 0.0;
           }
         }
       }
@@ -1054,7 +1090,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
             a = a * qa[c];
           }
 #if !COLATE_ABL_HAS(9)
-          wave_affine_scan(a, b, erows);
+          wave_affine_scan(a, b, erows, kFree ? aff_nosrc : nullptr);
 #endif
           // (b of lane l: T after the epochs of lanes 0..l, starting from T = 0)
           T[0] = dpp_d<WAVE_SHR1, 0xf, true>(0.0, b);  // T at the lane's first epoch (lane 0: 0)
@@ -1330,7 +1366,10 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     }
     // (for the loop conditions, see `kFree`; as scalar arithmetic on the compare's lane mask -- written as a shift of the mask the
     // compiler made a per-lane value and an exec-masked loop of it: 14 instructions at the top of every iteration)
-    if (kFree && kSteady) last_pos = (ballot64(lam_e[0] > 0.0) & last_bit) != 0ull;
+    if (kFree && kSteady) {
+      lim = ((ballot64(lam_e[0] > 0.0) & last_bit) != 0ull) ? lim : 0;
+      asm volatile("" : "+s"(lim));  // (opaque: the compiler otherwise turns the select back into a second loop condition)
+    }
     COLATE_STAMP(5)
     // stop rule, coal.cpp:3822 (evaluated after the update); uniform across the workgroup
     bool stop = false;
@@ -1355,23 +1394,31 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     using C1 = std::integral_constant<int, 1>;
     using CR = std::integral_constant<int, -1>;
 #define COLATE_STEADY(R, L, T, P)                             \
-  do {                                                        \
-    iteration(R{}, L{}, C0{}, T{}, C0{}, P{});                \
-  } while (__builtin_expect(++iter < n_steady && last_pos, 1))
+  {                                                           \
+    lim = n_steady;                                           \
+    do {                                                      \
+      iteration(R{}, L{}, C0{}, T{}, C0{}, P{});              \
+    } while (__builtin_expect(++iter < lim, 1));              \
+    if (kFree && lim == 0) last_pos = false;                  \
+  }
     // (the role B leader: the iterations that refresh the tail model are peeled out of the hot loop, which then carries
     // nothing of it but the held correction; same schedule as tail_due())
 #define COLATE_STEADY_B(R, L, T, P)                                                    \
   while (iter < n_steady && last_pos) {                                                \
     if (tail_due(iter)) {                                                              \
+      lim = n_steady;                                                                  \
       iteration(R{}, L{}, C0{}, T{}, C1{}, P{});                                       \
-      if (++iter >= n_steady || !last_pos) break;                                      \
+      ++iter;                                                                          \
+      if (kFree && lim == 0) last_pos = false;                                         \
+      if (iter >= n_steady || !last_pos) break;                                        \
     }                                                                                  \
-    int stop_ = tail_next_due(iter);                                                   \
-    if (stop_ > n_steady) stop_ = n_steady;                                            \
-    while (__builtin_expect(iter < stop_ && last_pos, 1)) {                            \
+    lim = tail_next_due(iter);                                                         \
+    if (lim > n_steady) lim = n_steady;                                                \
+    while (__builtin_expect(iter < lim, 1)) {                                          \
       iteration(R{}, L{}, C0{}, T{}, C0{}, P{});                                       \
       ++iter;                                                                          \
     }                                                                                  \
+    if (kFree && lim == 0) last_pos = false;                                           \
   }
     bool any_more_rows = false;
 #pragma unroll
@@ -1382,29 +1429,37 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     // Only up to 64 epochs: with two epochs per lane the extra loops cost the steady ones 2.5 % (1.53 -> 1.57 ms at
     // E = 122, every code placement; profiles/r02_placement.txt) -- there the general loop takes over at min_iter.
 #define COLATE_STEADY_LL(R, L, T, P)                          \
-  for (; iter < max_iter && last_pos; iter++) {               \
-    if (iteration(R{}, L{}, C1{}, T{}, C0{}, P{})) {          \
-      stopped = true;                                         \
-      break;                                                  \
+  if (last_pos) {                                             \
+    lim = max_iter;                                           \
+    for (; iter < lim; iter++) {                              \
+      if (iteration(R{}, L{}, C1{}, T{}, C0{}, P{})) {        \
+        stopped = true;                                       \
+        break;                                                \
+      }                                                       \
     }                                                         \
+    if (kFree && lim == 0) last_pos = false;                  \
   }
 #define COLATE_STEADY_LL_B(R, L, T, P)                                                 \
   while (iter < max_iter && !stopped && last_pos) {                                    \
     if (tail_due(iter)) {                                                              \
+      lim = max_iter;                                                                  \
       if (iteration(R{}, L{}, C1{}, T{}, C1{}, P{})) {                                 \
         stopped = true;                                                                \
         break;                                                                         \
       }                                                                                \
-      if (++iter >= max_iter || !last_pos) break;                                      \
+      ++iter;                                                                          \
+      if (kFree && lim == 0) last_pos = false;                                         \
+      if (iter >= max_iter || !last_pos) break;                                        \
     }                                                                                  \
-    int stop_ = tail_next_due(iter);                                                   \
-    if (stop_ > max_iter) stop_ = max_iter;                                            \
-    for (; iter < stop_ && last_pos; iter++) {                                         \
+    lim = tail_next_due(iter);                                                         \
+    if (lim > max_iter) lim = max_iter;                                                \
+    for (; iter < lim; iter++) {                                                       \
       if (iteration(R{}, L{}, C1{}, T{}, C0{}, P{})) {                                 \
         stopped = true;                                                                \
         break;                                                                         \
       }                                                                                \
     }                                                                                  \
+    if (kFree && lim == 0) last_pos = false;                                           \
   }
 #ifndef COLATE_LL_MAX_NCH
 #define COLATE_LL_MAX_NCH 1  // (epochs per lane up to which the log-likelihood-phase loops are compiled, see below)
