@@ -241,14 +241,14 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput, int wpe) {
   // The pad shifts everything behind it, the loops compiled per kind of wave included.
 #ifdef COLATE_EM_ILP_BUILD
   (void)tput;
-  // latency variant, max-ilp build, kernel ms for pads 0..7 (gpurun_out/r03z/pads5_* -> profiles/r03_placement.txt; final code of round 3):
-  // E=23 B=100 (the build without the register cap, two barriers) 0.936 0.942 0.993 0.977 0.957 0.967 0.944 0.942;
-  // E=23 B=400 (with the cap) 1.230 1.216 1.212 1.226 1.229 1.216 1.215 1.221; E=122 B=100 1.350 1.330 1.341 1.337 1.339 1.320 1.325 1.345
-  return nch == 1 ? (wpe == 2 ? 0 : 2) : 5;
+  // latency variant, max-ilp build, kernel ms for pads 0..7 (gpurun_out/r03z/pads6_* -> profiles/r03_placement.txt):
+  // E=23 B=100 (the build without the register cap, two barriers) 1.001 1.001 0.929 0.934 0.950 0.956 0.989 0.972;
+  // E=23 B=400 (with the cap) 1.202 1.203 1.205 1.202 1.219 1.196 1.207 1.203; E=122 B=100 1.317 1.325 1.330 1.327 1.331 1.334 1.319 1.308
+  return nch == 1 ? (wpe == 2 ? 2 : 5) : 7;
 #else
   (void)nch;
   if (!tput) return 6;  // latency variant, default build (not picked by colate_em_variant any more; COLATE_EM_VARIANT=latency)
-  return 3;             // throughput variant: E=23 B=4096 6.478 6.487 6.511 6.423 6.467 6.451 6.567 6.549 (round 3, final code)
+  return 3;             // throughput variant: E=23 B=4096 6.379 6.517 6.442 6.371 6.543 6.446 6.509 6.412 (round 3)
 #endif
 #endif
 }
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
           S_e[c] = 1.0 - cs_e[c] * 1e-3;
           omS_e[c] = cs_e[c] * 1e-3;
 #else
-          S_e[c] = em::em_exp_om_t(-cs_e[c], &omS_e[c], s_exptab);  // omS = 1 - S_e = sum_{j<e} exp(A_ep[j])
+          S_e[c] = em::em_exp_om_t<true>(cs_e[c], &omS_e[c], s_exptab);  // exp(-cs_e); omS = 1 - S_e = sum_{j<e} exp(A_ep[j])
 #endif
           // (no `if (ep_on)`: the rows are EPAD wide, entries beyond E are written with whatever the idle lanes hold and
           // never read for an epoch; a not-taken skip branch costs a lone wave 8 cycles, its exec bookkeeping 10 more)
@@ -780,15 +780,21 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
       const int wslot = 2 * (pos >> 6) + ROLE;  // entry of this (bin group, ROLE) in s_fail / s_ll: the latency variant's wave
       double o_w = 0, o_N = 0, o_D = 0, llp = 0.0;
       bool fail = false;
+      // the lanes whose normaliser failed, as scalar mask arithmetic where the branch-free paths know it (through the bool it took a
+      // v_cndmask and a v_cmp to get the mask back); `fail` itself is for the paths behind branches
+      unsigned long long fail_direct = 0;
+      bool have_fail_direct = false;
       if (ROLE == 0 && !COLATE_ABL_HAS(12)) {
         // ---- EM_shared, coal_EM.cpp:198-210, 263-287, WITHOUT exec-masked branches on `live` and `finite_pos(Sig)`: every lane
         // computes, the three results are selected at the end.  The two branches cost the wave 14 scalar / branch instructions per
         // iteration -- each an issue slot like an FP64 instruction -- against 6 v_cndmask here; a lane without data computes on
         // zeros (its gathers read epoch E's column, inside the rows) and is dropped.
         const double lk = have_lk ? lk_own : s_ep[G_LAM * EPAD + kb];
-        // 1 / lambda_k: the per-epoch value of P1, or the bin's own division (the same operation on the same operand)
-        const double ik = cross ? 1.0 / lk : s_ep[G_INV * EPAD + kb];
         const bool lpos = lk > 0;
+        // 1 / lambda_k: the per-epoch value of P1, or the bin's own division (the same operation on the same operand).
+        // A rate of 0 (coal_EM.cpp:198-210 skips such an epoch's terms): with the bin's own division the reciprocal is taken as 0,
+        // and Wp = S_k (1 - exp(-0)) = 0, Vp = X * 0 * S_k = 0 come out by themselves -- one select instead of two.
+        const double ik = cross ? (lpos ? 1.0 / lk : 0.0) : s_ep[G_INV * EPAD + kb];
         const double Sk = cross ? Sk_in : s_ep[G_S * EPAD + kb], PWk = cross ? PWk_in : s_ep[G_PW * EPAD + kb];
         const double Xak = cross ? em::em_div_known_rcp(tk + ik, ik, lk) : s_ep[G_XA * EPAD + kb];  // (t_k + 1/lambda)/(1/lambda), coal_EM.cpp:204
 #if COLATE_ABL_HAS(5)
@@ -801,19 +807,22 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
 #else
         const double Y = em::em_div_known_rcp(a_b + ik, ik, lk);  // (age + 1/lambda)/(1/lambda), coal_EM.cpp:204
 #endif
-        const double Wp = lpos ? Sk * (1.0 - qd) : 0.0;
+        const double Wp = (cross || lpos) ? Sk * (1.0 - qd) : 0.0;
         const double X = Xak - Y * qd;
-        const double Vp = lpos ? X * ik * Sk : 0.0;
+        const double Vp = (cross || lpos) ? X * ik * Sk : 0.0;  // (not cross: the gathered (t_k + 1/lambda)/(1/lambda) of a zero rate is a NaN)
         const double Sig = PWk + Wp;
         const bool fin = finite_pos(Sig), ok = live && fin;
-        const double r = em::em_rcp(Sig);
+        // (the reciprocal is the one thing that is not finite where the bin drops out -- Sig = 0 behind rates of zero --: with
+        // 0 in its place all three results are the exact zeros the branch used to leave, for one select instead of three)
+        const double r = ok ? em::em_rcp(Sig) : 0.0;
         const double nk = Wp * r;
         double dk = Vp * r + (-tk * nk);
         dk = __builtin_fmax(dk, 0.0);
-        o_w = ok ? cnt * r : 0.0;
-        o_N = ok ? cnt * nk : 0.0;
-        o_D = ok ? cnt * dk : 0.0;
-        fail = live && !fin;
+        o_w = cnt * r;
+        o_N = cnt * nk;
+        o_D = cnt * dk;
+        fail_direct = ballot64(live) & ~ballot64(fin);
+        have_fail_direct = true;
         if (need_ll) {
           COLATE_COLD();
           llp = ok ? cnt * em::em_log(Sig) : 0.0;
@@ -839,7 +848,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
 #else
         const double u = em::em_exp_t(-(lk * db), s_exptab);  // exp(-cumsum(t_{k+1}) + cumsum(age)), likewise
 #endif
-        const double pn = lpos ? 1.0 - u : 0.0;
+        const double pn = 1.0 - u;  // (a rate of 0: u = exp(-0) = 1 exactly, so this is the 0 a select would put here)
         const double bn = lpos ? (a_b + ik) - (tkn + ik) * u : 0.0;
         {  // the last epoch absorbs: normaliser = exp(-cs(age)) * ((1 - u) + u) = exp(-cs(age))
           double dk = bn + (-tk * pn + dtk * (1.0 - pn));
@@ -890,7 +899,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
       // bins whose normaliser failed (coal_EM.cpp:288-292, 461-465) drop out of the static counts
       // (s_fail: one byte per wave, the four bin groups of a role in one 32-bit word for the leader's single read)
       unsigned char* s_failb = reinterpret_cast<unsigned char*>(s_fail);
-      const unsigned long long fail_mask = ballot64(fail);
+      const unsigned long long fail_mask = have_fail_direct ? fail_direct : ballot64(fail);
+      if (have_fail_direct) fail = (fail_mask >> lane) & 1ull;  // (only read behind the rare branches below)
       if (TPUT) {  // (a wave serves several groups: publish every time)
         s_cfail[ROLE * APZ + pos] = fail ? cnt : 0.0;
         if (lane == 0) s_failb[ROLE * 4 + (pos >> 6)] = fail_mask ? 1 : 0;

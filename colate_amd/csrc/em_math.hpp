@@ -52,6 +52,18 @@ EM_HD double max_c(double x, double lo) {
 #endif
 }
 
+// max(-x, lo): the negation as the instruction's source modifier (the compiler cannot fold a negation into the operand of an
+// asm statement: it materialises -x first, two instructions)
+EM_HD double max_c_neg(double x, double lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double d;
+  asm("v_max_f64 %0, -%1, %2" : "=v"(d) : "v"(x), "s"(lo));
+  return d;
+#else
+  return __builtin_fmax(-x, lo);
+#endif
+}
+
 // Core of exp(): for xc >= -1100 returns y and k with exp(xc) = y * 2^k, y in [0.70, 1.42), and the
 // pieces (rh, tp) of exp(rh) - 1 = rh + tp that 1 - exp() needs near 0.  The polynomial is
 // evaluated Estrin-style (depth 5 instead of 12: the EM kernel is a chain of dependent
@@ -209,12 +221,14 @@ EM_HD double em_exp_t(double x, const double* tab) {
 }
 // exp(x) and 1 - exp(x) for x <= 0, the latter without cancellation near 0: with yh = 2^e th (exact) and
 // yl = 2^e (th p + tl), 1 - exp = (1 - yh) - yl, where 1 - yh is exact whenever exp(x) >= 1/2
+// (NEG: the argument is -x -- same operations on the same values, the negation riding on the first instruction)
+template <bool NEG = false>
 EM_HD double em_exp_om_t(double x, double* one_minus, const double* tab) {
 #ifdef COLATE_EXP_SERIES
   (void)tab;
-  return em_exp_om(x, one_minus);
+  return em_exp_om(NEG ? -x : x, one_minus);
 #endif
-  const double xc = max_c(x, -1100.0);
+  const double xc = NEG ? max_c_neg(x, -1100.0) : max_c(x, -1100.0);
   const ExpTab o = em_exp_tab_parts(xc, tab);
   const double yh = __builtin_ldexp(o.th, o.e);
   const double yl = __builtin_ldexp(fma_(o.th, o.p, o.tl), o.e);
