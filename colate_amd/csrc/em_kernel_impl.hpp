@@ -241,14 +241,14 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput, int wpe) {
   // The pad shifts everything behind it, the loops compiled per kind of wave included.
 #ifdef COLATE_EM_ILP_BUILD
   (void)tput;
-  // latency variant, max-ilp build, kernel ms for pads 0..7 (gpurun_out/r03z/pads6_* -> profiles/r03_placement.txt):
-  // E=23 B=100 (the build without the register cap, two barriers) 1.001 1.001 0.929 0.934 0.950 0.956 0.989 0.972;
-  // E=23 B=400 (with the cap) 1.202 1.203 1.205 1.202 1.219 1.196 1.207 1.203; E=122 B=100 1.317 1.325 1.330 1.327 1.331 1.334 1.319 1.308
-  return nch == 1 ? (wpe == 2 ? 2 : 5) : 7;
+  // latency variant, max-ilp build, kernel ms for pads 0..7 (gpurun_out/r03z/pads7_* -> profiles/r03_placement.txt):
+  // E=23 B=100 (the build without the register cap, two barriers) 0.913 0.922 0.904 0.919 0.885 0.927 0.947 0.933;
+  // E=23 B=400 (with the cap) 1.189 1.188 1.186 1.202 1.187 1.175 1.193 1.180; E=122 B=100 1.296 1.297 1.308 1.297 1.312 1.291 1.304 1.282
+  return nch == 1 ? (wpe == 2 ? 4 : 5) : 7;
 #else
   (void)nch;
   if (!tput) return 6;  // latency variant, default build (not picked by colate_em_variant any more; COLATE_EM_VARIANT=latency)
-  return 3;             // throughput variant: E=23 B=4096 6.379 6.517 6.442 6.371 6.543 6.446 6.509 6.412 (round 3)
+  return 1;             // throughput variant: E=23 B=4096 6.513 6.368 6.476 6.406 6.479 6.373 6.442 6.421 (round 3)
 #endif
 #endif
 }
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
 #if COLATE_ABL_HAS(7)
           const double inv = 2.0e4 - lam_e[c];
 #else
-          const double inv = 1.0 / lam_e[c];
+          const double inv = em::em_rcp_ieee(lam_e[c]);
 #endif
           const bool valid = vstat[c] && (lam_e[c] > 0);
           // exp(-cumsum[i+1] + cumsum[i]) of coal_EM.cpp:120, taken as exp(-lambda_e dt_e): the two arguments
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
         // 1 / lambda_k: the per-epoch value of P1, or the bin's own division (the same operation on the same operand).
         // A rate of 0 (coal_EM.cpp:198-210 skips such an epoch's terms): with the bin's own division the reciprocal is taken as 0,
         // and Wp = S_k (1 - exp(-0)) = 0, Vp = X * 0 * S_k = 0 come out by themselves -- one select instead of two.
-        const double ik = cross ? (lpos ? 1.0 / lk : 0.0) : s_ep[G_INV * EPAD + kb];
+        const double ik = cross ? (lpos ? em::em_rcp_ieee(lk) : 0.0) : s_ep[G_INV * EPAD + kb];
         const double Sk = cross ? Sk_in : s_ep[G_S * EPAD + kb], PWk = cross ? PWk_in : s_ep[G_PW * EPAD + kb];
         const double Xak = cross ? em::em_div_known_rcp(tk + ik, ik, lk) : s_ep[G_XA * EPAD + kb];  // (t_k + 1/lambda)/(1/lambda), coal_EM.cpp:204
 #if COLATE_ABL_HAS(5)
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
         // `lambda_k > 0` keep 1 / lambda_k = inf out -- so its three products are the +0.0 the branch used to leave there.
         const double lk = have_lk ? lk_own : s_ep[G_LAM * EPAD + kb];
         // 1 / lambda_k: the per-epoch value of P1, or the bin's own division (the same operation on the same operand)
-        const double ik = cross ? 1.0 / lk : s_ep[G_INV * EPAD + kb];
+        const double ik = cross ? em::em_rcp_ieee(lk) : s_ep[G_INV * EPAD + kb];
         const bool lpos = lk > 0;
         // -cumsum(age) at the merged grid (coal_EM.cpp:178-181): only the log-likelihood needs it
         auto neg_cs_age = [&]() {
@@ -1321,7 +1321,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
 #else
           double qn = N_e[c] / D_e[c];
 #endif
-          if (qn < p.rate_floor) qn = p.rate_floor;
+          qn = em::max_c(qn, p.rate_floor);  // (one v_max_f64; a NaN quotient -- 0 / 0 -- is a copying epoch and not used)
           cand[c] = (!copy && D_e[c] != 0) ? qn : lam_e[c];
         }
         // (the compare's own lane mask and the static mask of the live epoch lanes: scalar arithmetic from here on)

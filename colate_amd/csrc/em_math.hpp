@@ -251,6 +251,26 @@ EM_HD double em_rcp(double x) {
 #endif
 }
 
+// 1 / x, the IEEE (correctly rounded) reciprocal: the very sequence the compiler expands `1.0 / x` to on gfx950 -- v_rcp_f64, two
+// Newton steps, the quotient estimate (= y for a numerator of 1), one Markstein correction with the exact residual, v_div_fixup for
+// x = 0, inf, NaN -- minus the two v_div_scale and the scaling of v_div_fmas, which only act on operands beyond 2^+-768 or so: four
+// instructions fewer for the same bits on every rate the EM can hold (tests/test_gpu_em_math.py compares it with the device's own
+// division over the rates' range and beyond).  Host: the division itself.
+EM_HD double em_rcp_ieee(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma_(-x, y, 1.0);
+  y = fma_(y, e, y);
+  e = fma_(-x, y, 1.0);
+  y = fma_(y, e, y);
+  const double r = fma_(-x, y, 1.0);
+  const double q = fma_(r, y, y);
+  return __builtin_amdgcn_div_fixup(q, x, 1.0);
+#else
+  return 1.0 / x;
+#endif
+}
+
 // n / d where a reciprocal y of d is already known to ~1 ulp -- here d = fl(1/lambda), y = lambda.
 // Quotient estimate + two Markstein corrections with the exact residual: equal to the IEEE
 // (correctly rounded) quotient in every one of 2e7 random trials of the shapes the kernel uses

@@ -2,9 +2,10 @@
 // of doubles, for tests/test_gpu_em_math.py: em_exp / em_exp_om / em_log are the same source on host and device,
 // but em_rcp, fma_cc, max_c and ldexp/frexp take device-only code (v_rcp_f64 + Newton, inline v_fma_f64 / v_max_f64,
 // v_ldexp_f64 / v_frexp_*), so "identical on gfx950" is checked here bit for bit instead of assumed.
-//   em_math_device IN OUT : IN = n doubles (x) followed by n doubles (aux); OUT = 10 arrays of n doubles:
+//   em_math_device IN OUT : IN = n doubles (x) followed by n doubles (aux); OUT = 11 arrays of n doubles:
 //   em_exp(x) | em_exp_om(x).value | em_exp_om(x).one_minus | em_log(|x|) | em_rcp(|x|) | em_div_known_rcp(aux + 1/|x|, 1/|x|, |x|)
 //   | 1/|x| by IEEE division on the device | em_exp_t(x) | em_exp_om_t(x).value | em_exp_om_t(x).one_minus
+//   | em_rcp_ieee(|x|)
 //   (the table-driven exp the kernel uses, here with the table read from device memory instead of LDS)
 #include <hip/hip_runtime.h>
 
@@ -30,6 +31,7 @@ __global__ void probe(int n, const double* __restrict__ x, const double* __restr
   out[7 * (size_t)n + i] = em::em_exp_t(v, em::kExpTableDevice);
   out[8 * (size_t)n + i] = em::em_exp_om_t(v, &om_t, em::kExpTableDevice);
   out[9 * (size_t)n + i] = om_t;
+  out[10 * (size_t)n + i] = em::em_rcp_ieee(a);
 }
 
 int main(int argc, char** argv) {
@@ -40,7 +42,7 @@ int main(int argc, char** argv) {
   const long bytes = ftell(f);
   fseek(f, 0, SEEK_SET);
   const int n = (int)(bytes / 16);
-  std::vector<double> in(2 * (size_t)n), out(10 * (size_t)n);
+  std::vector<double> in(2 * (size_t)n), out(11 * (size_t)n);
   if (fread(in.data(), 8, 2 * (size_t)n, f) != 2 * (size_t)n) return 2;
   fclose(f);
   double *d_in, *d_out;

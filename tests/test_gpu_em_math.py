@@ -35,6 +35,9 @@ def test_device_math_equals_host_build(tmp_path):
         -np.exp(rng.uniform(np.log(1e-14), np.log(1100), 60000)),       # the kernel's exp arguments: -(rate * time)
         rng.uniform(-2.0 ** -10, 0, 8000), -rng.uniform(0, 2.0 ** -30, 2000),
         [-0.0, -1e-300, -745.13, -745.2, -800.0, -1100.0, -1e5, -708.4, -709.0, -1.0, -0.5, -np.log(2.0)],
+        # for the reciprocals: many more magnitudes over the rates' range and beyond, and the significands next to 1 and 2
+        -np.exp(rng.uniform(np.log(1e-12), np.log(1e4), 400000)),
+        -np.ldexp(np.repeat([2.0 - 2.0 ** -52, 2.0 - 2.0 ** -51, 1.0 + 2.0 ** -52, 1.0 + 2.0 ** -51, 1.5, 1.0], 52), np.tile(np.arange(-40, 12), 6)),
     ])
     n = x.size
     aux = np.exp(rng.uniform(np.log(0.05), np.log(1e7), n))  # ages / epoch starts for the division shape (t + 1/lambda)/(1/lambda)
@@ -42,7 +45,7 @@ def test_device_math_equals_host_build(tmp_path):
     (tmp_path / "in.bin").write_bytes(np.concatenate([x, aux]).tobytes())
     exe = os.path.join(ROOT, "colate_amd", "bin", "em_math_device")
     subprocess.check_call([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
-    out = np.frombuffer((tmp_path / "out.bin").read_bytes(), dtype=np.float64).reshape(10, n)
+    out = np.frombuffer((tmp_path / "out.bin").read_bytes(), dtype=np.float64).reshape(11, n)
     h = _host(tmp_path)
     y = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
     P = lambda a: a.ctypes.data_as(dp)  # noqa: E731
@@ -61,6 +64,10 @@ def test_device_math_equals_host_build(tmp_path):
     pos = a > 1e-290
     inv = 1.0 / a[pos]
     assert np.array_equal(out[6][pos], inv), "device IEEE division differs from the host's"
+    # em_rcp_ieee: the division's own instruction sequence without the operand scaling -- the same doubles wherever no scaling is
+    # due (every magnitude here: 1e-290 .. 1e5), and an infinity for 0
+    assert np.array_equal(out[10][pos], inv), "em_rcp_ieee is not the IEEE reciprocal"
+    assert np.all(np.isinf(out[10][a == 0.0]))  # (the harness hands -0.0 through: -inf, as the division gives)
     ulp = np.abs(out[4][pos] - inv) / np.spacing(inv)
     assert ulp.max() <= 1.0, ulp.max()  # em_rcp: hardware seed + two Newton steps, not correctly rounded
     lam = a[(a >= 5e-9) & (a <= 1e-1)]
