@@ -14,7 +14,8 @@
 // double-precision instructions, and BASELINE configs put <= 256 replicates on a
 // 256-CU GPU (one workgroup per CU), so the kernel is built for LATENCY: what
 // costs is the number of instructions ONE wave has to issue per iteration
-// (a lone wave issues a dependent v_fma_f64 every ~7 cycles, tools/ubench.hip).
+// (a lone wave issues one instruction per 4.3 cycles whatever it is -- FP64, DPP, scalar,
+// s_nop -- and in order: tools/ubench.hip, tools/ubench_fetch2.hip).
 // The work of an iteration is therefore split by ROLE over waves that run
 // concurrently on different SIMDs:
 //
@@ -26,7 +27,9 @@
 // 64, so 2*NB waves; waves without bins retire before the loop, which keeps the
 // s_barrier cheap), epoch e in lane e / NCH (slot e % NCH; NCH = 1, 2, 4 for up to 64, 128, 256 epochs) of the role leaders,
 // and three workgroup barriers per iteration (epoch values -> bins -> per-epoch
-// sums -> rates).  Per-epoch sums of the per-bin terms are reduced in registers
+// sums -> rates) -- two in the build for batches that leave every workgroup a CU to
+// itself at up to 64 epochs, where each wave of role A computes the epoch values it
+// needs itself (`kFree` in em_kernel).  Per-epoch sums of the per-bin terms are reduced in registers
 // (row-segmented DPP) and handed over through an LDS tile at static "tail" slots.
 // For batches far beyond the CU count the same code is instantiated as a THROUGHPUT
 // variant (template flag TPUT: two waves per replicate that loop over the bin groups;
