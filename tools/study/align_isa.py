@@ -31,7 +31,10 @@ this script's own).  Output: assembly for the same assembler.
 import re
 import sys
 
-MIN_RUN = 6
+import os
+MIN_RUN = int(os.environ.get("ALIGN_NOP_MIN_RUN", "6"))            # s_nop only in front of at least this many 8-byte instructions (1000: never)
+PROMOTE_MIN_RUN = int(os.environ.get("ALIGN_PROMOTE_MIN_RUN", "1"))  # re-encode only in front of at least this many (second experiment: 8)
+ALIGN_HEADS = os.environ.get("ALIGN_HEADS", "1") == "1"
 src, dst = sys.argv[1], sys.argv[2]
 lines = open(src).read().split("\n")
 
@@ -85,7 +88,7 @@ for i, l in enumerate(lines):
         run4 = []
         out.append(l)
         continue
-    if i in loop_heads and off % 32 != 0:
+    if ALIGN_HEADS and i in loop_heads and off % 32 != 0:
         out.append("\t.p2align 5")
         off = (off + 31) // 32 * 32
         run4 = []
@@ -104,7 +107,16 @@ for i, l in enumerate(lines):
         if off % 8 == 4:
             stats["misaligned"] += 1
             fixed = False
-            for k in reversed(run4):
+            follow0 = 0  # 8-byte instructions from here on, back to back
+            for j in range(i, n):
+                s_ = size_of(lines[j])
+                if s_ == 0 and not label_re.match(lines[j]) and not lines[j].strip().startswith("."):
+                    continue
+                if s_ % 8 == 0 and s_ > 0:
+                    follow0 += 1
+                else:
+                    break
+            for k in (reversed(run4) if follow0 >= PROMOTE_MIN_RUN else []):
                 if promotable.match(out[k]):
                     out[k] = enc_re.sub("; (re-encoded as VOP3 by align_isa.py)", out[k].replace("_e32", "_e64", 1))
                     off += 4
