@@ -1439,8 +1439,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     // (a wave with an epoch spanning more than two rows of data bins stays in the general loop)
     // ... and the iterations from min_iter on (log-likelihood and stop test in every one) in a second set of loops
     // compiled the same way: runs on sparse tables go on for up to 1e5 iterations there (1.55 -> 1.31 us per iteration).
-    // Only up to 64 epochs: with two epochs per lane the extra loops cost the steady ones 2.5 % (1.53 -> 1.57 ms at
-    // E = 122, every code placement; profiles/r02_placement.txt) -- there the general loop takes over at min_iter.
+    // (Round 2 compiled them up to 64 epochs only: with two epochs per lane the extra loops cost the steady ones 2.5 % then,
+    // 1.53 -> 1.57 ms at E = 122.  Round 3, with the placement re-tuned: 1.270 against 1.282 ms for the steady state and 1.65
+    // against 2.07 us per iteration from min_iter on -- gpurun_out/r03z/ll2_e122.txt -> profiles/r03_placement.txt.)
 #define COLATE_STEADY_LL(R, L, T, P)                          \
   if (last_pos) {                                             \
     lim = max_iter;                                           \
@@ -1475,7 +1476,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     if (kFree && lim == 0) last_pos = false;                                           \
   }
 #ifndef COLATE_LL_MAX_NCH
-#define COLATE_LL_MAX_NCH 1  // (epochs per lane up to which the log-likelihood-phase loops are compiled, see below)
+#define COLATE_LL_MAX_NCH 2  // (epochs per lane up to which the log-likelihood-phase loops are compiled, see below)
 #endif
 #ifdef COLATE_NO_LL_LOOPS  // (A/B switch: the iterations from min_iter on in the general loop)
 #define COLATE_BOTH(R, L, T, P)                               \

@@ -27,7 +27,8 @@ def worker(out):
     rng = np.random.default_rng(5)
     for name, bins, B, kw in (("e23_b100", "3,7,0.2", 100, {}), ("e23_b400", "3,7,0.2", 400, {}), ("e23_b3000", "3,7,0.2", 3000, dict(max_iter=300, min_iter=100)),
                               ("e122_b100", "2,7.95,0.05", 100, {}), ("e122_b600", "2,7.95,0.05", 600, dict(max_iter=300, min_iter=100)),
-                              ("e202_b50", "2,7.95,0.03", 50, dict(max_iter=300, min_iter=100)), ("e43_b64", "3,7,0.1", 64, {})):
+                              ("e202_b50", "2,7.95,0.03", 50, dict(max_iter=300, min_iter=100)), ("e43_b64", "3,7,0.1", 64, {}),
+                              ("e122_b64_ll", "2,7.95,0.05", 64, dict(max_iter=400, min_iter=50)), ("e23_b64_ll", "3,7,0.2", 64, dict(max_iter=400, min_iter=50))):
         ep, _ = ol.epochs_from_bins(bins)
         csh, cns = workloads.bootstrap_tables(grid, B, nb=115, scale=1.0)
         r, it, ll, fl = colate_amd.em_batch(grid, csh, cns, ep, **kw)
