@@ -251,7 +251,7 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput, int wpe) {
 #else
   (void)nch;
   if (!tput) return 6;  // latency variant, default build (not picked by colate_em_variant any more; COLATE_EM_VARIANT=latency)
-  return 1;             // throughput variant: E=23 B=4096 6.513 6.368 6.476 6.406 6.479 6.373 6.442 6.421 (round 3)
+  return 4;             // throughput variant: E=23 B=4096 6.395 6.415 6.430 6.398 6.226 6.376 6.404 6.413; B=1024 1.923 1.940 1.937 1.944 1.928 1.942 1.928 1.928 (round 3, gpurun_out/r03z/pads12_*)
 #endif
 #endif
 }
@@ -615,8 +615,22 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   // when the last rate is not positive -- one s_cselect in the iteration and a plain counted loop around it (as a second loop
   // condition it cost every wave twelve scalar instructions and two branches per iteration)
   int lim = 0;
-  const unsigned long long last_bit = 1ull << ((E - 1) & 63);  // (free mode has one epoch per lane: the last epoch's lane)
-  if (kFree) last_pos = (ballot64(lam_e[0] > 0.0) & last_bit) != 0ull;
+  // (the throughput variant makes the same assumption in its per-kind loops -- it spares its role-B wave the branches around the
+  // cold paths of a zero last rate: 6.18 against 6.33 ms at B = 4096 --; for the other latency builds it measured no gain)
+  constexpr bool kAssumeAbsorbing = kFree || TPUT;
+  // (the last epoch's lane, per slot: 0 in the slots that do not hold it)
+  unsigned long long last_bit[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; c++) last_bit[c] = (((E - 1) & (NCH - 1)) == c) ? 1ull << (((E - 1) >> kSlotShift) & 63) : 0ull;
+  auto last_rate_positive = [&]() {
+    unsigned long long pos = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) pos |= ballot64(lam_e[c] > 0.0) & last_bit[c];
+    return pos != 0ull;
+  };
+  const unsigned long long last_bit1 = 1ull << ((E - 1) & 63);  // (one epoch per lane: the last epoch's lane)
+  if (kFree) last_pos = (ballot64(lam_e[0] > 0.0) & last_bit1) != 0ull;
+  if (TPUT) last_pos = last_rate_positive();
   auto tail_due = [&](int it) { return (it & (it - 1)) == 0; };
   auto tail_next_due = [&](int it) { return it <= 1 ? it : (1 << (32 - __builtin_clz((unsigned)(it - 1)))); };  // first due iteration >= it
   auto iteration = [&](auto role_c, auto leader_c, auto ll_c, auto track_c, auto refresh_c, auto p1_c) __attribute__((always_inline)) -> bool {
@@ -761,8 +775,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     // (from this wave's own copy of the rates -- every wave runs the M-step --, not from LDS: the read and its wait were the
     // first thing behind barrier 1 in role B's waves)
     // (the free-mode loops compiled per kind of wave run only while it does: the loop conditions below)
-    bool absorbing = kFree && kSteady;
-    if (!(kFree && kSteady)) {
+    bool absorbing = kAssumeAbsorbing && kSteady;
+    if (!(kAssumeAbsorbing && kSteady)) {
       const int cl = (E - 1) & (NCH - 1), ll_ = (E - 1) >> kSlotShift;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
@@ -1379,8 +1393,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     }
     // (for the loop conditions, see `kFree`; as scalar arithmetic on the compare's lane mask -- written as a shift of the mask the
     // compiler made a per-lane value and an exec-masked loop of it: 14 instructions at the top of every iteration)
-    if (kFree && kSteady) {
-      lim = ((ballot64(lam_e[0] > 0.0) & last_bit) != 0ull) ? lim : 0;
+    if (kAssumeAbsorbing && kSteady) {
+      // (the two-barrier build keeps its one-slot form: the same test, but this kernel's code is tuned to its placement)
+      lim = (kFree ? ((ballot64(lam_e[0] > 0.0) & last_bit1) != 0ull) : last_rate_positive()) ? lim : 0;
       asm volatile("" : "+s"(lim));  // (opaque: the compiler otherwise turns the select back into a second loop condition)
     }
     COLATE_STAMP(5)
@@ -1412,7 +1427,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     do {                                                      \
       iteration(R{}, L{}, C0{}, T{}, C0{}, P{});              \
     } while (__builtin_expect(++iter < lim, 1));              \
-    if (kFree && lim == 0) last_pos = false;                  \
+    if (kAssumeAbsorbing && lim == 0) last_pos = false;                  \
   }
     // (the role B leader: the iterations that refresh the tail model are peeled out of the hot loop, which then carries
     // nothing of it but the held correction; same schedule as tail_due())
@@ -1422,7 +1437,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
       lim = n_steady;                                                                  \
       iteration(R{}, L{}, C0{}, T{}, C1{}, P{});                                       \
       ++iter;                                                                          \
-      if (kFree && lim == 0) last_pos = false;                                         \
+      if (kAssumeAbsorbing && lim == 0) last_pos = false;                                         \
       if (iter >= n_steady || !last_pos) break;                                        \
     }                                                                                  \
     lim = tail_next_due(iter);                                                         \
@@ -1431,7 +1446,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
       iteration(R{}, L{}, C0{}, T{}, C0{}, P{});                                       \
       ++iter;                                                                          \
     }                                                                                  \
-    if (kFree && lim == 0) last_pos = false;                                           \
+    if (kAssumeAbsorbing && lim == 0) last_pos = false;                                           \
   }
     bool any_more_rows = false;
 #pragma unroll
@@ -1451,7 +1466,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
         break;                                                \
       }                                                       \
     }                                                         \
-    if (kFree && lim == 0) last_pos = false;                  \
+    if (kAssumeAbsorbing && lim == 0) last_pos = false;                  \
   }
 #define COLATE_STEADY_LL_B(R, L, T, P)                                                 \
   while (iter < max_iter && !stopped && last_pos) {                                    \
@@ -1462,7 +1477,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
         break;                                                                         \
       }                                                                                \
       ++iter;                                                                          \
-      if (kFree && lim == 0) last_pos = false;                                         \
+      if (kAssumeAbsorbing && lim == 0) last_pos = false;                                         \
       if (iter >= max_iter || !last_pos) break;                                        \
     }                                                                                  \
     lim = tail_next_due(iter);                                                         \
@@ -1473,7 +1488,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
         break;                                                                         \
       }                                                                                \
     }                                                                                  \
-    if (kFree && lim == 0) last_pos = false;                                           \
+    if (kAssumeAbsorbing && lim == 0) last_pos = false;                                           \
   }
 #ifndef COLATE_LL_MAX_NCH
 #define COLATE_LL_MAX_NCH 2  // (epochs per lane up to which the log-likelihood-phase loops are compiled, see below)
@@ -1577,13 +1592,15 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
 #undef COLATE_STEADY
     // ... and where the per-kind loops of that phase are not built (more than 64 epochs), one loop compiled for "log-likelihood
     // needed" only: no cost for the steady loops, 2.20 -> 2.08 us per iteration at E = 122
-    if constexpr (NCH > COLATE_LL_MAX_NCH) if (!(any_more_rows || third_row)) {
-      for (; iter < max_iter; iter++) {
+    if constexpr (NCH > COLATE_LL_MAX_NCH) if (!(any_more_rows || third_row) && last_pos) {
+      lim = max_iter;
+      for (; iter < lim; iter++) {
         if (iteration(CR{}, CR{}, C1{}, CR{}, CR{}, CR{})) {
           stopped = true;
           break;
         }
       }
+      if (kAssumeAbsorbing && lim == 0) last_pos = false;
     }
   }
   for (; !stopped && iter < max_iter; iter++) {
