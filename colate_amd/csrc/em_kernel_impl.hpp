@@ -190,8 +190,11 @@ __device__ __forceinline__ unsigned long long stamp() {
     st_acc[i] += now_ - st_prev;            \
     st_prev = now_;                         \
   }
+// ... and absolute stamps along the prologue and around the loops (wave 0 of every replicate; written to out_den at the end)
+#define COLATE_PSTAMP(i) pro_t[i] = stamp();
 #else
 #define COLATE_STAMP(i)
+#define COLATE_PSTAMP(i)
 #endif
 
 // Timing-only ablations for tools/em_phase_probe.hip (-DCOLATE_ABL=<bit mask>): each bit removes one
@@ -244,14 +247,14 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput, int wpe) {
   // The pad shifts everything behind it, the loops compiled per kind of wave included.
 #ifdef COLATE_EM_ILP_BUILD
   (void)tput;
-  // latency variant, max-ilp build, kernel ms for pads 0..7 (gpurun_out/r03z/pads7_* -> profiles/r03_placement.txt):
-  // E=23 B=100 (the build without the register cap, two barriers) 0.913 0.922 0.904 0.919 0.885 0.927 0.947 0.933;
-  // E=23 B=400 (with the cap) 1.189 1.188 1.186 1.202 1.187 1.175 1.193 1.180; E=122 B=100 1.296 1.297 1.308 1.297 1.312 1.291 1.304 1.282
-  return nch == 1 ? (wpe == 2 ? 4 : 5) : 7;
+  // latency variant, max-ilp build, kernel ms for pads 0..7 (gpurun_out/r03z/pads13_* -> profiles/r03_placement.txt; final code of round 3):
+  // E=23 B=100 (the build without the register cap, two barriers) 0.892 0.906 0.898 0.886 0.878 0.890 0.907 0.890;
+  // E=23 B=400 (with the cap) 1.136 1.137 1.145 1.139 1.141 1.149 1.144 1.137; E=122 B=100 1.233 1.221 1.237 1.233 1.228 1.231 1.230 1.226
+  return nch == 1 ? (wpe == 2 ? 4 : 0) : 1;
 #else
   (void)nch;
   if (!tput) return 6;  // latency variant, default build (not picked by colate_em_variant any more; COLATE_EM_VARIANT=latency)
-  return 4;             // throughput variant: E=23 B=4096 6.395 6.415 6.430 6.398 6.226 6.376 6.404 6.413; B=1024 1.923 1.940 1.937 1.944 1.928 1.942 1.928 1.928 (round 3, gpurun_out/r03z/pads12_*)
+  return 3;             // throughput variant: E=23 B=4096 6.297 6.309 6.316 6.213 6.351 6.364 6.327 6.360 (round 3, gpurun_out/r03z/pads13_*)
 #endif
 #endif
 }
@@ -321,6 +324,10 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trace_t0)::"memory");
 #endif
   // ------------------------------------------------------------------ prologue
+#ifdef COLATE_EM_STAMPS
+  unsigned long long pro_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  COLATE_PSTAMP(0)
   const double* epochs = p.epochs + (size_t)rep * p.epochs_stride;
   for (int i = tid; i < EPAD + 1; i += blockDim.x) s_t[i] = (i < E) ? epochs[i] : 0.0;
   for (int i = tid; i < kRows * EPAD + 2 * kNumBinArrays * APZ + 4 * EPAD + 4 * APZ; i += blockDim.x) s_ep[i] = 0.0;
@@ -336,35 +343,51 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   }
   if (tid < em::kExpTableDoubles) s_exptab[tid] = em::kExpTableDevice[tid];
   __syncthreads();
+  COLATE_PSTAMP(1)
   for (int t = tid; t < AP; t += blockDim.x) {
     int kb = E;  // padding: beyond every epoch
+    bool has_sh = false, has_ns = false;
     if (t < A) {
       const double a = p.age_grid[t];
       const double c1 = p.cnt_sh[(size_t)rep * A + t];
       const double c2 = p.cnt_ns[(size_t)rep * A + t];
       const double csh = (c1 > 0) ? c1 : 0.0;  // coal.cpp:3706, 3719: only counts > 0 are visited
       const double cns = (c2 > 0) ? c2 : 0.0;
-      kb = E - 1;  // coal_EM.cpp:60-95: largest e with epochs[e] <= age (strict `age < epochs[e]`)
-      for (int e = 0; e < E; e++) {
-        if (a < s_t[e]) {
-          kb = e - 1;
-          break;
+      // coal_EM.cpp:60-95: largest e with epochs[e] <= age (strict `age < epochs[e]`): the epoch starts are non-decreasing
+      // (include/colate_amd.h), so the first e with age < epochs[e] comes from a bisection -- the linear scan of the reference
+      // was 8 (12) of the 34 (59) us this prologue took at 23 (122) epochs, and the prologue 5 % (8 %) of the whole kernel
+      int first_gt = 0;  // number of epochs with start <= age
+      for (int len = E; len > 0;) {
+        const int half = len >> 1;
+        if (!(a < s_t[first_gt + half])) {
+          first_gt += half + 1;
+          len -= half + 1;
+        } else {
+          len = half;
         }
       }
+      kb = first_gt - 1;
       if (kb < 0) kb = 0;  // host validates age >= epochs[0]; never taken
       s_cnt[t] = csh;
       s_cnt[APZ + t] = cns;
       s_age[t] = a;  // (throughput variant: per-bin statics; both: the tail model's refresh)
-      if (csh > 0 || cns > 0) {
-        atomicMin(&s_misc[0], t);
-        atomicMax(&s_misc[1], t + 1);
-        atomicAdd(&s_misc[3], (csh > 0 ? 1 : 0) + (cns > 0 ? 1 : 0));  // (bin, kind) pairs the reference evaluates: for the epilogue
+      has_sh = csh > 0;
+      has_ns = cns > 0;
+    }
+    {  // first / last bin with data and the number of (bin, kind) pairs the reference evaluates (for the epilogue): one atomic per
+       // wave from the lane masks (AP is a multiple of 64: a wave's lanes run this loop together) instead of three per lane
+      const unsigned long long m_sh = ballot64(has_sh), m_ns = ballot64(has_ns), m_any = m_sh | m_ns;
+      if (m_any != 0 && lane == 0) {
+        atomicMin(&s_misc[0], t + (int)__builtin_ctzll(m_any));
+        atomicMax(&s_misc[1], t + 64 - (int)__builtin_clzll(m_any));
+        atomicAdd(&s_misc[3], (int)__builtin_popcountll(m_sh) + (int)__builtin_popcountll(m_ns));
       }
     }
     s_kb[t] = kb;
   }
   if (tid == 0) s_kb[AP] = E + 1;
   __syncthreads();
+  COLATE_PSTAMP(2)
   int nzlo = s_misc[0], nzhi = s_misc[1];
   if (nzlo >= nzhi) {  // no data at all: keep one (empty) group so that the run mirrors the reference
     nzlo = 0;
@@ -398,6 +421,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
       if (MODE == 0 && wave == 0) p.out_rates[(size_t)rep * E + e] = lam_e[c];
     }
   }
+  COLATE_PSTAMP(3)
   if (tid == 0) s_ll[10] = (nzhi > nzlo) ? (double)s_kb[nzhi - 1] : -1.0;  // epoch of the oldest bin that carries data
   // bin statics: this lane's bin (compacted to the bins that carry data) and role
   const int pos = grp * kWave + lane;  // position in the compacted tile
@@ -467,8 +491,18 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   // x3 margin on top, which flagged one epoch more than the checker finds unstable; with the tail model below the flagged
   // epochs themselves stay within the reference's noise envelope, and the margin went.)
   constexpr double kResolvedRatio = 1.0e10;
+  COLATE_PSTAMP(4)
   double c_all = 0.0;
-  for (int b = 0; b < A; b++) c_all += s_cnt[role * APZ + b];
+  // (ascending; the counts outside [nzlo, nzhi) are 0, x + 0.0 == x, and the row is zero up to AP: eight loads in flight per
+  // round, added in order -- one load per addition waited ~75 cycles for each)
+  for (int b = nzlo; b < nzhi; b += 8) {
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = s_cnt[role * APZ + b + j];
+#pragma unroll
+    for (int j = 0; j < 8; j++) c_all += v[j];
+  }
+  COLATE_PSTAMP(5)
   // role A: dt_e * residue of the shared bins (0 in the last epoch, which has no dt_e * integ term).  Role B: the tail
   // model's correction R_e to the not-shared integ mass of the epoch (see `tail model` in P3), refreshed there.
   double eta_e[NCH];
@@ -479,17 +513,43 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
     const int e = ep_of(c);
+    // The bins of epoch e are [lo, hi) -- the ages ascend, so the bins' epochs do --: two bisections of s_kb instead of a walk over
+    // all bins per lane, which was 22 (42) us per launch at 23 (122) epochs.  An epoch without bins: lo == hi, no tail slots.
     int lo = A, hi = 0, n_before = 0;
     double c_later = 0.0;
     if (ep_on[c]) {
-      for (int b = 0; b < A; b++) {
-        const int k = s_kb[b];
-        if (k == e) {
-          if (b < lo) lo = b;
-          hi = b + 1;
+      lo = hi = 0;
+      for (int len = A; len > 0;) {  // first b with s_kb[b] >= e
+        const int half = len >> 1;
+        if (s_kb[lo + half] < e) {
+          lo += half + 1;
+          len -= half + 1;
+        } else {
+          len = half;
         }
-        if (k > e) c_later += s_cnt[role * APZ + b];
-        if (k < e && b >= nzlo && b < nzhi) n_before++;
+      }
+      for (int len = A; len > 0;) {  // first b with s_kb[b] > e
+        const int half = len >> 1;
+        if (s_kb[hi + half] <= e) {
+          hi += half + 1;
+          len -= half + 1;
+        } else {
+          len = half;
+        }
+      }
+      const int lo_c = lo < nzlo ? nzlo : (lo > nzhi ? nzhi : lo);
+      n_before = lo_c - nzlo;  // compacted positions in earlier epochs
+    }
+    {  // counts of the later bins, b >= hi, summed in ascending order as before (a bin outside the data has a count of 0, and
+       // x + 0.0 == x): one walk over the bins with data for the whole wave, every lane adding from its own hi on
+      int b0 = __builtin_amdgcn_readfirstlane(hi);  // (lane 0 holds the slot's earliest epoch: the smallest hi)
+      if (b0 < nzlo) b0 = nzlo;
+      for (int b = b0; b < nzhi; b += 8) {  // (eight loads in flight; the row is zero from nzhi up to AP)
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = s_cnt[role * APZ + b + j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) c_later += (ep_on[c] && b + j >= hi) ? v[j] : 0.0;
       }
     }
     C0[c] = c_later;
@@ -516,6 +576,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     third_row |= (ballot64(slot2[c] != AP) != 0);
   }
   __syncthreads();
+  COLATE_PSTAMP(6)
   if (!TPUT && grp >= NB) return;  // waves without bins retire; later barriers count the remaining waves only
   const bool leader = (grp == 0);
   // The wave that keeps the verdict's history masks in the M-step and writes the verdict and the rates at the end: a
@@ -591,6 +652,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
 
 #ifdef COLATE_EM_STAMPS
   unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  COLATE_PSTAMP(7)
   unsigned long long st_prev = stamp();
 #endif
   // Code placement: the time of an iteration moves by up to 5 % with the position of the loop's code relative to 32-byte
@@ -1609,6 +1671,11 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   }
 
 #ifdef COLATE_EM_STAMPS
+  COLATE_PSTAMP(8)
+  if (p.out_den && tid == 0 && MODE == 0) {  // diagnostic build: wave 0's absolute stamps along the prologue in place of out_den
+    unsigned long long* dbg2 = reinterpret_cast<unsigned long long*>(p.out_den) + (size_t)rep * 10;
+    for (int i = 0; i < 9; i++) dbg2[i] = pro_t[i];
+  }
   if (p.out_num && lane == 0 && MODE == 0 && wave < 4) {  // diagnostic build: per-wave phase cycles in place of out_num
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out_num) + ((size_t)rep * 4 + wave) * 16;
     for (int i = 0; i < 16; i++) dbg[i] = st_acc[i];

@@ -49,6 +49,11 @@ int main(int argc, char** argv) {
   a.max_iter = 1002, a.min_iter = 1000000;  // ablation builds: fixed number of iterations (results are meaningless)
 #endif
   a.out_rates = d_rates, a.out_iters = d_it, a.out_ll = d_ll, a.out_flags = d_fl, a.out_num = d_dbg;
+  double* d_pro;
+  hipMalloc(&d_pro, (size_t)B * 10 * 8);
+  hipMemset(d_pro, 0, (size_t)B * 10 * 8);
+  a.out_den = d_pro;
+  if (argc > 3) a.max_iter = atoi(argv[3]), a.min_iter = 1000000;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   colate_em_launch(a, nullptr);
@@ -64,6 +69,17 @@ int main(int argc, char** argv) {
   hipMemcpy(dbg.data(), d_dbg, dbg.size() * 8, hipMemcpyDeviceToHost);
   hipMemcpy(it.data(), d_it, B * 4, hipMemcpyDeviceToHost);
   printf("launch: %s, %.3f ms, iters[0]=%d\n", hipGetErrorString(err), ms, it[0]);
+  {
+    std::vector<unsigned long long> pro((size_t)B * 10);
+    hipMemcpy(pro.data(), d_pro, pro.size() * 8, hipMemcpyDeviceToHost);
+    const char* pn[8] = {"LDS clear + epoch starts", "bins: counts, ages, epoch of each bin", "epoch statics, starting rates", "bin statics", "total counts", "per-epoch bin ranges + later counts (+ barrier)", "verdict constants, masks", "all iterations"};
+    printf("prologue of replicate 0, wave 0 (cycles at 2.4 GHz; us):\n");
+    for (int i = 0; i < 8; i++) printf("   %-48s %8llu  %6.2f us\n", pn[i], pro[i + 1] - pro[i], (pro[i + 1] - pro[i]) / 2400.0);
+    unsigned long long first = ~0ull, last = 0;
+    for (int r = 0; r < B; r++) { if (pro[(size_t)r * 10] < first) first = pro[(size_t)r * 10]; if (pro[(size_t)r * 10 + 8] > last) last = pro[(size_t)r * 10 + 8]; }
+    printf("   first workgroup start to last workgroup at its epilogue: %.2f us; workgroup starts spread over %.2f us\n", (last - first) / 2400.0,
+           ([&] { unsigned long long mx = 0; for (int r = 0; r < B; r++) if (pro[(size_t)r * 10] > mx) mx = pro[(size_t)r * 10]; return (mx - first) / 2400.0; })());
+  }
 #ifndef COLATE_EM_STAMPS
   return 0;
 #endif
