@@ -60,6 +60,12 @@ SIGNATURES = {
     "colate_bootstrap_counts_device": (c_int, [c_int, c_int, c_int, c_void_p, c_double] + [c_void_p] * 9),
     "colate_bootstrap_em_batch": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_double] + [c_void_p] * 7
                                   + [c_int, c_int, c_double, c_double] + [c_void_p] * 6),
+    "colate_bootstrap_counts_from_weights": (c_int, [c_int, c_int, c_int, c_void_p, c_double] + [c_void_p] * 7),
+    "colate_bootstrap_em_batch_groups": (c_int, [c_int, c_int, c_int, c_int] + [c_void_p] * 10
+                                         + [c_int, c_int, c_double, c_double] + [c_void_p] * 6),
+    "colate_bootstrap_counts_groups_device": (c_int, [c_int] * 6 + [c_void_p] * 14),
+    "colate_bootstrap_em_batch_groups_allgather": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p] * 10
+                                                   + [c_int, c_int, c_double, c_double] + [c_void_p] * 4),
     "colate_release_workspace": (c_int, []),
     "colate_shard_bounds": (c_int, [c_int, c_int, c_int, ip, ip]),
     "colate_comm_unique_id": (c_int, [c_void_p]),

@@ -16,16 +16,16 @@
 
 namespace {
 
-__global__ __launch_bounds__(COLATE_EM_MAX_A) void bootstrap_kernel(
-    int nb, int A, const double* __restrict__ age_grid, double age, const double* __restrict__ weights,
+// one replicate: `w` = its nb block weights, the four tables [nb][A], `out_sh` / `out_ns` = its two rows of counts
+__device__ __forceinline__ void bootstrap_replicate(
+    int nb, int A, const double* __restrict__ age_grid, double age, const double* __restrict__ w,
     const double* __restrict__ sh_block, const double* __restrict__ ns_block,
     const double* __restrict__ sh_emp_block, const double* __restrict__ ns_emp_block,
-    double* __restrict__ cnt_sh, double* __restrict__ cnt_ns, int* __restrict__ status) {
+    double* __restrict__ out_sh, double* __restrict__ out_ns, int* __restrict__ status) {
   __shared__ double s_she[COLATE_EM_MAX_A], s_F[COLATE_EM_MAX_A], s_grid[COLATE_EM_MAX_A];
   __shared__ double s_fcount, s_normf;
   __shared__ int s_bin_start;
-  const int rep = blockIdx.x, b = threadIdx.x;
-  const double* w = weights + (size_t)rep * nb;
+  const int b = threadIdx.x;
   double sh = 0.0, ns = 0.0, she = 0.0, nse = 0.0;
   if (b < A) {
     for (int j = 0; j < nb; j++) {
@@ -80,12 +80,55 @@ __global__ __launch_bounds__(COLATE_EM_MAX_A) void bootstrap_kernel(
     }
   }
   if (b < A) {
-    cnt_sh[(size_t)rep * A + b] = sh;
-    cnt_ns[(size_t)rep * A + b] = ns;
+    out_sh[b] = sh;
+    out_ns[b] = ns;
   }
 }
 
+__global__ __launch_bounds__(COLATE_EM_MAX_A) void bootstrap_kernel(
+    int nb, int A, const double* __restrict__ age_grid, double age, const double* __restrict__ weights,
+    const double* __restrict__ sh_block, const double* __restrict__ ns_block,
+    const double* __restrict__ sh_emp_block, const double* __restrict__ ns_emp_block,
+    double* __restrict__ cnt_sh, double* __restrict__ cnt_ns, int* __restrict__ status) {
+  const int rep = blockIdx.x;
+  bootstrap_replicate(nb, A, age_grid, age, weights + (size_t)rep * nb, sh_block, ns_block, sh_emp_block, ns_emp_block,
+                      cnt_sh + (size_t)rep * A, cnt_ns + (size_t)rep * A, status);
+}
+
+// Batched all-pairs: row r = group * B + replicate of G (target, reference) pairs, each with its
+// own block tables (nb[g] blocks from block_off[g] on in the concatenated tables), weights (from weight_off[g] on:
+// [B][nb[g]]) and sample age.  The launch covers rows [row_lo, row_lo + gridDim.x); the group arrays start at group
+// `group_first`; row r writes counts row r - row_lo.
+__global__ __launch_bounds__(COLATE_EM_MAX_A) void bootstrap_groups_kernel(
+    int B, int row_lo, int group_first, int A, const double* __restrict__ age_grid, const int* __restrict__ group_nb,
+    const long long* __restrict__ group_block_off, const long long* __restrict__ group_weight_off,
+    const double* __restrict__ group_age, const double* __restrict__ weights, const double* __restrict__ sh_block,
+    const double* __restrict__ ns_block, const double* __restrict__ sh_emp_block,
+    const double* __restrict__ ns_emp_block, double* __restrict__ cnt_sh, double* __restrict__ cnt_ns,
+    int* __restrict__ status) {
+  const int r = row_lo + blockIdx.x;
+  const int g = r / B - group_first, rep = r % B;
+  const int nb = group_nb[g];
+  const size_t t0 = (size_t)group_block_off[g] * A;
+  bootstrap_replicate(nb, A, age_grid, group_age[g], weights + group_weight_off[g] + (size_t)rep * nb, sh_block + t0,
+                      ns_block + t0, sh_emp_block + t0, ns_emp_block + t0, cnt_sh + (size_t)blockIdx.x * A,
+                      cnt_ns + (size_t)blockIdx.x * A, status);
+}
+
 }  // namespace
+
+hipError_t colate_bootstrap_groups_launch(int B, int row_lo, int rows, int group_first, int A, const double* age_grid,
+                                          const int* group_nb, const long long* group_block_off,
+                                          const long long* group_weight_off, const double* group_age,
+                                          const double* weights, const double* sh_block, const double* ns_block,
+                                          const double* sh_emp_block, const double* ns_emp_block, double* cnt_sh,
+                                          double* cnt_ns, int* status, hipStream_t stream) {
+  const int threads = (A + 63) & ~63;
+  hipLaunchKernelGGL(bootstrap_groups_kernel, dim3(rows), dim3(threads), 0, stream, B, row_lo, group_first, A, age_grid,
+                     group_nb, group_block_off, group_weight_off, group_age, weights, sh_block, ns_block, sh_emp_block,
+                     ns_emp_block, cnt_sh, cnt_ns, status);
+  return hipGetLastError();
+}
 
 hipError_t colate_bootstrap_launch(int B, int nb, int A, const double* age_grid, double age,
                                    const double* weights, const double* sh_block, const double* ns_block,

@@ -518,6 +518,97 @@ int colate_bootstrap_em_batch(int B, int nb, int E, int A, const double* age_gri
   return COLATE_OK;
 }
 
+int colate_bootstrap_counts_groups_device(int G, int B, int group_first, int row_lo, int row_hi, int A,
+                                          const double* age_grid, const int* group_nb,
+                                          const long long* group_block_off, const long long* group_weight_off,
+                                          const double* group_age, const double* weights, const double* sh_block,
+                                          const double* ns_block, const double* sh_emp_block,
+                                          const double* ns_emp_block, double* cnt_shared, double* cnt_notshared,
+                                          int* status, void* hip_stream) {
+  if (G < 1 || B < 1 || A < 2 || A > COLATE_EM_MAX_A || group_first < 0 || row_lo < 0 || row_hi < row_lo)
+    return fail(COLATE_EINVAL, "bad sizes G=%d B=%d A=%d rows [%d, %d)", G, B, A, row_lo, row_hi);
+  if (row_hi > row_lo && (row_lo / B < group_first || (row_hi - 1) / B >= group_first + G))
+    return fail(COLATE_EINVAL, "rows [%d, %d) lie outside groups [%d, %d)", row_lo, row_hi, group_first, group_first + G);
+  if (!age_grid || !group_nb || !group_block_off || !group_weight_off || !group_age || !weights || !sh_block ||
+      !ns_block || !sh_emp_block || !ns_emp_block || !cnt_shared || !cnt_notshared || !status)
+    return fail(COLATE_EINVAL, "NULL pointer argument");
+  if (row_hi == row_lo) return COLATE_OK;
+  mark_device_touched();
+  hipError_t e = colate_bootstrap_groups_launch(B, row_lo, row_hi - row_lo, group_first, A, age_grid, group_nb,
+                                                group_block_off, group_weight_off, group_age, weights, sh_block,
+                                                ns_block, sh_emp_block, ns_emp_block, cnt_shared, cnt_notshared,
+                                                status, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "bootstrap kernel launch");
+  return COLATE_OK;
+}
+
+int colate_bootstrap_em_batch_groups(int G, int B, int E, int A, const double* age_grid, const int* group_nb,
+                                     const double* group_age, const double* weights, const double* sh_block,
+                                     const double* ns_block, const double* sh_emp_block,
+                                     const double* ns_emp_block, const double* epochs, const double* init_rates,
+                                     int max_iter, int min_iter, double rel_tol, double rate_floor,
+                                     double* out_rates, int* out_iters, double* out_loglik, int* out_flags,
+                                     double* out_cnt_shared, double* out_cnt_notshared) {
+  if (G < 0 || B < 1) return fail(COLATE_EINVAL, "bad sizes G=%d B=%d", G, B);
+  if ((long long)G * B > 0x7fffffffLL) return fail(COLATE_ELIMIT, "G x B = %lld rows", (long long)G * B);
+  const int R = G * B;
+  if (int rc = check_sizes(R, E, A)) return rc;
+  if (A < 2) return fail(COLATE_EINVAL, "bad sizes A=%d", A);
+  if (!age_grid || !group_nb || !group_age || !weights || !sh_block || !ns_block || !sh_emp_block || !ns_emp_block ||
+      !epochs || !init_rates || !out_rates || !out_iters || !out_loglik || !out_flags)
+    return fail(COLATE_EINVAL, "NULL pointer argument");
+  if (max_iter < 1) return fail(COLATE_EINVAL, "max_iter must be >= 1");
+  std::vector<long long> block_off(G), weight_off(G);
+  long long nblocks = 0, nweights = 0;
+  for (int g = 0; g < G; g++) {
+    if (group_nb[g] < 1) return fail(COLATE_EINVAL, "group %d has %d genome blocks", g, group_nb[g]);
+    if (int rc = check_grids(E, A, age_grid, epochs + (size_t)g * E)) return rc;
+    block_off[g] = nblocks, weight_off[g] = nweights;
+    nblocks += group_nb[g], nweights += (long long)B * group_nb[g];
+  }
+  if (int rc = ensure_device()) return rc;
+  if (G == 0) return COLATE_OK;
+  ProfRange range("colate_bootstrap_em_batch_groups: H2D + bootstrap kernel + EM kernel + D2H");
+  const size_t nT = (size_t)nblocks * A, nRA = (size_t)R * A, nRE = (size_t)R * E;
+  // epochs and starting rates per row (the EM kernel's per-replicate layout)
+  std::vector<double> row_ep(nRE), row_init(nRE);
+  for (int r = 0; r < R; r++) {
+    std::memcpy(row_ep.data() + (size_t)r * E, epochs + (size_t)(r / B) * E, (size_t)E * sizeof(double));
+    std::memcpy(row_init.data() + (size_t)r * E, init_rates + (size_t)(r / B) * E, (size_t)E * sizeof(double));
+  }
+  Stage st;
+  const int i_grid = st.in(age_grid, A), i_w = st.in(weights, (size_t)nweights);
+  const int i_t0 = st.in(sh_block, nT), i_t1 = st.in(ns_block, nT), i_t2 = st.in(sh_emp_block, nT), i_t3 = st.in(ns_emp_block, nT);
+  const int i_nb = st.in(group_nb, G), i_bo = st.in(block_off.data(), G), i_wo = st.in(weight_off.data(), G),
+            i_age = st.in(group_age, G);
+  const int i_ep = st.in(row_ep.data(), nRE), i_init = st.in(row_init.data(), nRE);
+  const int zero = 0;
+  const int i_status = st.in(&zero, 1);
+  const int o_rates = st.out(out_rates, nRE), o_ll = st.out(out_loglik, R), o_iters = st.out(out_iters, R),
+            o_flags = st.out(out_flags, R);
+  const bool want_counts = out_cnt_shared || out_cnt_notshared;
+  const int c_sh = want_counts ? st.out(out_cnt_shared, nRA) : st.scratch<double>(nRA);
+  const int c_ns = want_counts ? st.out(out_cnt_notshared, nRA) : st.scratch<double>(nRA);
+  int status_host = 0;
+  const int o_status = st.out(&status_host, 1);
+  if (int rc = st.commit()) return rc;
+  if (int rc = colate_bootstrap_counts_groups_device(G, B, 0, 0, R, A, st.dev<double>(i_grid), st.dev<int>(i_nb),
+                                                     st.dev<long long>(i_bo), st.dev<long long>(i_wo), st.dev<double>(i_age),
+                                                     st.dev<double>(i_w), st.dev<double>(i_t0), st.dev<double>(i_t1),
+                                                     st.dev<double>(i_t2), st.dev<double>(i_t3), st.dev<double>(c_sh),
+                                                     st.dev<double>(c_ns), st.dev<int>(i_status), st.stream()))
+    return rc;
+  if (int rc = colate_em_batch_device(R, E, A, st.dev<double>(i_grid), st.dev<double>(c_sh), st.dev<double>(c_ns),
+                                      st.dev<double>(i_ep), 1, st.dev<double>(i_init), 1, max_iter, min_iter, rel_tol,
+                                      rate_floor, st.dev<double>(o_rates), st.dev<int>(o_iters), st.dev<double>(o_ll),
+                                      st.dev<int>(o_flags), st.stream()))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(st.dev<int>(o_status), st.dev<int>(i_status), sizeof(int), hipMemcpyDeviceToDevice, st.stream()));
+  if (int rc = st.finish()) return rc;
+  if (status_host) return fail(COLATE_EINVAL, "sample age outside the age grid");
+  return COLATE_OK;
+}
+
 int colate_em_batch_rows(int B, int E, int A, const double* age_grid, const double* cnt_shared,
                          const double* cnt_notshared, const double* epochs, const double* init_rates,
                          int max_iter, int min_iter, double rel_tol, double rate_floor,

@@ -341,4 +341,92 @@ int colate_bootstrap_em_batch_allgather(void* comm, int B, int nb, int E, int A,
   return COLATE_OK;
 }
 
+int colate_bootstrap_em_batch_groups_allgather(void* comm, int G, int B, int group_first, int group_count, int E, int A,
+                                               const double* age_grid, const int* group_nb, const double* group_age,
+                                               const double* weights, const double* sh_block, const double* ns_block,
+                                               const double* sh_emp_block, const double* ns_emp_block,
+                                               const double* epochs, const double* init_rates, int max_iter,
+                                               int min_iter, double rel_tol, double rate_floor, double* out_rates,
+                                               int* out_iters, double* out_loglik, int* out_flags) {
+  Comm* c = static_cast<Comm*>(comm);
+  if (!c) return fail(COLATE_EINVAL, "NULL communicator");
+  if (G < 0 || B < 1 || E < 1 || A < 2 || E > COLATE_MAX_EPOCHS || A > COLATE_MAX_AGE_BINS || (long long)G * B > 0x7fffffffLL)
+    return fail(COLATE_EINVAL, "bad sizes G=%d B=%d E=%d A=%d", G, B, E, A);
+  if (!age_grid || !out_rates || !out_iters || !out_loglik || !out_flags) return fail(COLATE_EINVAL, "NULL pointer argument");
+  if (max_iter < 1) return fail(COLATE_EINVAL, "max_iter must be >= 1");
+  const int R = G * B;
+  int lo = 0, hi = 0;
+  colate_shard_bounds(R, c->nranks, c->rank, &lo, &hi);
+  // A rank with rows must bring exactly the groups they belong to.  A mismatch is this rank's own error and is found on
+  // its inputs alone, but the other ranks may be fine: it joins the collective with its code (run_and_gather) instead of
+  // leaving them waiting.
+  int early = COLATE_OK;
+  if (hi > lo) {
+    if (group_first != lo / B || group_count != (hi - 1) / B - lo / B + 1)
+      early = fail(COLATE_EINVAL, "rank %d computes rows [%d, %d) = groups [%d, %d], but was given groups [%d, %d)", c->rank, lo, hi,
+                   lo / B, (hi - 1) / B, group_first, group_first + group_count);
+    else if (!group_nb || !group_age || !weights || !sh_block || !ns_block || !sh_emp_block || !ns_emp_block || !epochs || !init_rates)
+      early = fail(COLATE_EINVAL, "NULL pointer argument");
+    for (int g = 0; g < group_count && !early; g++) {
+      if (group_nb[g] < 1) early = fail(COLATE_EINVAL, "group %d has %d genome blocks", group_first + g, group_nb[g]);
+      if (!early) early = check_grids(E, A, age_grid, epochs + (size_t)g * E);
+    }
+  }
+  const std::string early_msg = early ? colate_last_error() : "";
+  if (int rc = ensure_device()) return rc;
+  if (R == 0) return COLATE_OK;
+  Upload up;
+  int* d_status = nullptr;
+  int rc = run_and_gather(
+      c, R, E, out_rates, out_iters, out_loglik, out_flags,
+      [&](int n, int row_lo, double* d_rates, double* d_ll, int* d_iters, int* d_flags, hipStream_t s) {
+        if (early) return fail(early, "%s", early_msg.c_str());
+        std::vector<long long> block_off(group_count), weight_off(group_count);
+        long long nblocks = 0, nweights = 0;
+        for (int g = 0; g < group_count; g++) {
+          block_off[g] = nblocks, weight_off[g] = nweights;
+          nblocks += group_nb[g], nweights += (long long)B * group_nb[g];
+        }
+        const size_t nT = (size_t)nblocks * A;
+        std::vector<double> row_ep((size_t)n * E), row_init((size_t)n * E);
+        for (int r = 0; r < n; r++) {
+          const size_t g = (size_t)((row_lo + r) / B - group_first);
+          std::memcpy(row_ep.data() + (size_t)r * E, epochs + g * E, (size_t)E * sizeof(double));
+          std::memcpy(row_init.data() + (size_t)r * E, init_rates + g * E, (size_t)E * sizeof(double));
+        }
+        double *d_grid, *d_w, *d_t0, *d_t1, *d_t2, *d_t3, *d_ep, *d_init, *d_sh, *d_ns, *d_age;
+        int* d_nb;
+        long long *d_bo, *d_wo;
+        const int zero = 0;
+        if (int r = up.put(age_grid, A, &d_grid, s)) return r;
+        if (int r = up.put(weights, (size_t)nweights, &d_w, s)) return r;
+        if (int r = up.put(sh_block, nT, &d_t0, s)) return r;
+        if (int r = up.put(ns_block, nT, &d_t1, s)) return r;
+        if (int r = up.put(sh_emp_block, nT, &d_t2, s)) return r;
+        if (int r = up.put(ns_emp_block, nT, &d_t3, s)) return r;
+        if (int r = up.put(group_nb, group_count, &d_nb, s)) return r;
+        if (int r = up.put(block_off.data(), group_count, &d_bo, s)) return r;
+        if (int r = up.put(weight_off.data(), group_count, &d_wo, s)) return r;
+        if (int r = up.put(group_age, group_count, &d_age, s)) return r;
+        if (int r = up.put(row_ep.data(), (size_t)n * E, &d_ep, s)) return r;
+        if (int r = up.put(row_init.data(), (size_t)n * E, &d_init, s)) return r;
+        if (int r = up.put<double>(nullptr, (size_t)n * A, &d_sh, s)) return r;
+        if (int r = up.put<double>(nullptr, (size_t)n * A, &d_ns, s)) return r;
+        if (int r = up.put(&zero, 1, &d_status, s)) return r;
+        HIP_TRY(hipStreamSynchronize(s));  // (the host vectors of this scope leave it)
+        if (int r = colate_bootstrap_counts_groups_device(group_count, B, group_first, row_lo, row_lo + n, A, d_grid, d_nb, d_bo, d_wo,
+                                                          d_age, d_w, d_t0, d_t1, d_t2, d_t3, d_sh, d_ns, d_status, s))
+          return r;
+        return colate_em_batch_device(n, E, A, d_grid, d_sh, d_ns, d_ep, 1, d_init, 1, max_iter, min_iter, rel_tol, rate_floor,
+                                      d_rates, d_iters, d_ll, d_flags, s);
+      });
+  if (rc) return rc;
+  if (d_status) {
+    int status = 0;
+    HIP_TRY(hipMemcpy(&status, d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (status) return fail(COLATE_EINVAL, "sample age outside the age grid");
+  }
+  return COLATE_OK;
+}
+
 }  // extern "C"

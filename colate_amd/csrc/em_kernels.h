@@ -50,3 +50,11 @@ hipError_t colate_bootstrap_launch(int B, int nb, int A, const double* age_grid,
                                    const double* weights, const double* sh_block, const double* ns_block,
                                    const double* sh_emp_block, const double* ns_emp_block, double* cnt_sh,
                                    double* cnt_ns, int* status, hipStream_t stream);
+// the same for rows [row_lo, row_lo + rows) of G groups x B replicates with per-group tables / weights / ages
+// (device arrays indexed from group `group_first`; bootstrap_groups_kernel)
+hipError_t colate_bootstrap_groups_launch(int B, int row_lo, int rows, int group_first, int A, const double* age_grid,
+                                          const int* group_nb, const long long* group_block_off,
+                                          const long long* group_weight_off, const double* group_age,
+                                          const double* weights, const double* sh_block, const double* ns_block,
+                                          const double* sh_emp_block, const double* ns_emp_block, double* cnt_sh,
+                                          double* cnt_ns, int* status, hipStream_t stream);

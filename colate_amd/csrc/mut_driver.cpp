@@ -30,6 +30,7 @@
 #include <cstring>
 #include <ctime>
 #include <fstream>
+#include <functional>
 #include <iomanip>
 #include <iostream>
 #include <map>
@@ -41,8 +42,9 @@
 
 #include "colate_amd.h"
 #include "colate_internal.h"
+#include "mut_feeder.h"
 
-namespace {
+namespace colate_drv {
 
 // ------------------------------------------------------------------ options
 // Same option names as Colate.cpp:11-45 (unknown options are an error there too:
@@ -53,11 +55,6 @@ namespace {
 // `--counts_out FILE` (write the bootstrap count tables in the reference's .colate_mat layout,
 // 17 significant digits), `--counts_only` (stop after that; needs no GPU) and `--write_colate_mat` (write
 // <output>.colate_mat exactly as the reference does for BCF/BAM inputs, coal.cpp:3336-3343, 3453-3470).
-struct Options {
-  std::map<std::string, std::string> kv;
-  bool has(const std::string& k) const { return kv.count(k) > 0; }
-  const std::string& get(const std::string& k) const { return kv.at(k); }
-};
 
 const char* const kValueOptions[] = {
     "mode", "anc", "mut", "target_bcf", "reference_bcf", "target_mask", "reference_mask",
@@ -147,11 +144,6 @@ void print_help() {
 }
 
 // ------------------------------------------------------------------ stage timing (COLATE_TIMING=1: one stderr line at the end)
-struct StageTimes {
-  double parse_mut = 0, table_fill = 0, wait_for_parser = 0, bootstrap_em = 0;
-  bool on = std::getenv("COLATE_TIMING") != nullptr;
-  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-};
 StageTimes g_times;
 
 // ------------------------------------------------------------------ gz text
@@ -192,15 +184,6 @@ class GzText {
 };
 
 // ------------------------------------------------------------------ .mut rows
-// Only the columns parse_tmptmp looks at (mutations.cpp:77-246):
-// snp;pos;dist;rs;tree;branches;is_not_mapping;is_flipped;age_begin;age_end;anc/der;...
-struct MutRow {
-  int pos = 0;
-  int num_branches = 0;
-  int flipped = 0;
-  float age_begin = 0.0f, age_end = 0.0f;  // stored as float in the reference (mutations.hpp:21)
-  std::string mutation_type = "NA";
-};
 
 // (the readers run on their own threads: leave without running the static destructors under the other threads' feet)
 [[noreturn]] void reader_exit() {
@@ -283,7 +266,7 @@ inline bool parse_mut_line(char* b, char* e, MutRow& r) {
   return true;
 }
 
-bool read_mut_file(const std::string& filename, std::vector<MutRow>& rows) {
+bool for_each_mut_row(const std::string& filename, const std::function<void(const MutRow&)>& sink) {
   gzFile f = gzopen(filename.c_str(), "rb");
   if (!f) f = gzopen((filename + ".gz").c_str(), "rb");
   if (!f) {
@@ -291,7 +274,7 @@ bool read_mut_file(const std::string& filename, std::vector<MutRow>& rows) {
     reader_exit();  // mutations.cpp:265-268: exit(1)
   }
   gzbuffer(f, 1 << 20);
-  rows.clear();
+  MutRow row;
   // inflate in 4 MB pieces and cut lines in place (no per-line std::string, no per-field copies)
   std::vector<char> buf((4u << 20) + 1);
   size_t have = 0;
@@ -313,8 +296,9 @@ bool read_mut_file(const std::string& filename, std::vector<MutRow>& rows) {
       if (!header_done) {
         header_done = true;
       } else {
-        rows.emplace_back();
-        if (!parse_mut_line(b, nl, rows.back())) mut_line_error(std::string(b, nl));
+        row.mutation_type = "NA";
+        if (!parse_mut_line(b, nl, row)) mut_line_error(std::string(b, nl));
+        sink(row);
       }
       b = (nl < end) ? nl + 1 : end;
       if (b >= end) break;
@@ -324,6 +308,11 @@ bool read_mut_file(const std::string& filename, std::vector<MutRow>& rows) {
   }
   gzclose(f);
   return true;
+}
+
+bool read_mut_file(const std::string& filename, std::vector<MutRow>& rows) {
+  rows.clear();
+  return for_each_mut_row(filename, [&rows](const MutRow& r) { rows.push_back(r); });
 }
 
 // Reader thread: inflates and tokenises the .mut files in order, at most two chromosomes ahead of the table fill.  The
@@ -462,21 +451,7 @@ struct TmpStream {
   bool eof_ = false;
 };
 
-struct BlockTables {  // one entry per genome block; emp = row 0 of the reference's A*A tables
-  std::vector<std::vector<double>> sh, ns, sh_emp, ns_emp;
-  void add_block(int A) {
-    sh.emplace_back(A, 0.0);
-    ns.emplace_back(A, 0.0);
-    sh_emp.emplace_back(A, 0.0);
-    ns_emp.emplace_back(A, 0.0);
-  }
-};
 
-inline int age_bin_index(double x, double C) {  // coal.cpp:2265, 2284
-  const double v = std::round(std::log(10 * x) * C);
-  if (!(v > -2e9)) return 0;  // log(0) = -inf: the reference's (int) cast yields INT_MIN -> max(0, .) = 0
-  return std::max(0, (int)v + 1);
-}
 
 // ---- sampling of the mutation ages, off the main thread ---------------------------------------------------------------
 // Every used SNP spreads its weight over 100 ages drawn uniformly between age_begin and age_end (coal.cpp:2260-2295), each
@@ -600,69 +575,6 @@ inline bool canonical_fast_ok() {
   return ok;
 }
 
-// std::mt19937's recurrence with the state regenerated 624 words at a time in loops the compiler vectorises (the library's
-// operator() does the same work word by word: 7.5 ns per word on the build container, against ~2 here).  Same sequence by
-// construction; UniformStream checks it against the library's generator before it trusts it.  State goes in and out of a
-// std::mt19937 through its textual form (the 624 words and the position, [rand.eng.mers]).
-class BulkMt19937 {
- public:
-  bool load(const std::mt19937& g) {
-    std::ostringstream os;
-    os << g;
-    std::istringstream is(os.str());
-    for (int i = 0; i < 624; i++)
-      if (!(is >> x_[i])) return false;
-    if (!(is >> p_) || p_ > 624) return false;
-    return true;
-  }
-  bool store(std::mt19937& g) const {
-    std::ostringstream os;
-    for (int i = 0; i < 624; i++) os << x_[i] << ' ';
-    os << p_;
-    std::istringstream is(os.str());
-    return static_cast<bool>(is >> g);
-  }
-  // the next n 32-bit outputs
-  void generate(uint32_t* out, size_t n) {
-    while (n) {
-      if (p_ >= 624) twist();
-      const size_t k = std::min(n, (size_t)(624 - p_));
-      const uint32_t* x = x_ + p_;
-      for (size_t i = 0; i < k; i++) {  // tempering
-        uint32_t y = x[i];
-        y ^= y >> 11;
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= y >> 18;
-        out[i] = y;
-      }
-      out += k, n -= k, p_ += (uint32_t)k;
-    }
-  }
-  void discard(unsigned long long n) {
-    uint32_t tmp[624];
-    while (n) {
-      const size_t k = (size_t)std::min<unsigned long long>(n, 624);
-      generate(tmp, k);
-      n -= k;
-    }
-  }
-
- private:
-  static uint32_t mix(uint32_t a, uint32_t b) {
-    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-  }
-  void twist() {
-    for (int i = 0; i < 227; i++) x_[i] = x_[i + 397] ^ mix(x_[i], x_[i + 1]);          // (old words only)
-    for (int i = 227; i < 454; i++) x_[i] = x_[i - 227] ^ mix(x_[i], x_[i + 1]);        // (new words of the first loop)
-    for (int i = 454; i < 623; i++) x_[i] = x_[i - 227] ^ mix(x_[i], x_[i + 1]);        // (new words of the second)
-    x_[623] = x_[396] ^ mix(x_[623], x_[0]);
-    p_ = 0;
-  }
-  uint32_t x_[624];
-  uint32_t p_ = 624;
-};
 
 // The uniforms themselves, on a thread of their own: the stream does not depend on the data, only HOW MANY of its values the
 // fill takes does.  The thread runs ahead on a copy of the run's generator, filling chunks of kChunk doubles, and keeps the
@@ -985,7 +897,7 @@ int fill_tables_from_tmp(const std::vector<std::string>& chr_names,
                          const std::string& ref_file, const std::vector<std::string>& target_masks,
                          const std::vector<std::string>& ref_masks, double C, std::mt19937& rng,
                          int num_bases_per_block, int A, BlockTables& tab,
-                         std::map<std::string, std::vector<MutRow>>* mut_cache = nullptr) {
+                         std::map<std::string, std::vector<MutRow>>* mut_cache) {
   const int nt = sample_threads();
   if (nt > 0) {
     const std::mt19937 rng0 = rng;
@@ -1034,17 +946,6 @@ bool file_exists(const std::string& p) {
   return true;
 }
 
-void write_counts_file(const std::string& path, int B, int A, const std::vector<double>& grid,
-                       const double* csh, const double* cns);
-
-// `--ranks N`: this process is rank `rank` of `nranks` (run_ranked forks them); the 128-byte RCCL id travels from
-// rank 0 to the others through the launcher's pipes.
-struct RankCtx {
-  bool ranked = false;  // launched by run_ranked (also with one rank: the RCCL path with a communicator of one)
-  int rank = 0, nranks = 1;
-  int fd_id_out = -1;  // rank 0: writes the id here
-  int fd_id_in = -1;   // ranks > 0: read it here
-};
 RankCtx g_rank;
 
 bool write_all(int fd, const void* buf, size_t n) {
@@ -1064,6 +965,31 @@ bool read_all(int fd, void* buf, size_t n) {
     p += k, n -= (size_t)k;
   }
   return true;
+}
+
+void print_usage_footer() {  // coal.cpp:3852-3861
+  rusage usage;
+  getrusage(RUSAGE_SELF, &usage);
+  std::cerr << "CPU Time spent: " << usage.ru_utime.tv_sec << "." << std::setfill('0') << std::setw(6)
+            << usage.ru_utime.tv_usec << "s; Max Memory usage: " << usage.ru_maxrss / 1000.0 << "Mb." << std::endl;
+  std::cerr << "---------------------------------------------------------" << std::endl << std::endl;
+}
+
+// coal.cpp:3295-3313: with --chr one .mut per listed chromosome (<mut>_chr<name>.mut), else the --mut path verbatim and
+// the chromosome name ""
+void chromosome_files(const Options& opt, std::vector<std::string>& names, std::vector<std::string>& mut_files) {
+  if (opt.has("chr")) {
+    GzText is_chr;
+    if (!is_chr.open(opt.get("chr"))) std::cerr << "Error while opening file " << opt.get("chr") << std::endl;
+    std::string line;
+    while (is_chr.getline(line)) {
+      names.push_back(line);
+      mut_files.push_back(opt.get("mut") + "_chr" + line + ".mut");
+    }
+  } else {
+    names.push_back("");
+    mut_files.push_back(opt.get("mut"));
+  }
 }
 
 int run_mut(const Options& opt) {
@@ -1366,24 +1292,10 @@ int run_mut(const Options& opt) {
     return 1;
   }
 
-  rusage usage;  // coal.cpp:3852-3861
-  getrusage(RUSAGE_SELF, &usage);
-  std::cerr << "CPU Time spent: " << usage.ru_utime.tv_sec << "." << std::setfill('0') << std::setw(6)
-            << usage.ru_utime.tv_usec << "s; Max Memory usage: " << usage.ru_maxrss / 1000.0 << "Mb." << std::endl;
-  std::cerr << "---------------------------------------------------------" << std::endl << std::endl;
+  print_usage_footer();
   return 0;
 }
 
-
-// ------------------------------------------------------------------ --pairs (batched all-pairs)
-// Not in the reference CLI (one run per pair there, re-parsing every .mut each time).  Every pair
-// is processed exactly as its own `--mode mut` run would be (RNG re-seeded from --seed, own block
-// tables, own epochs when a sample is ancient); the EM of ALL replicates of ALL pairs is one launch
-// per distinct epoch count.
-struct PairSpec {
-  std::string target, reference, output;
-  double target_age = 0, ref_age = 0;
-};
 
 void write_counts_file(const std::string& path, int B, int A, const std::vector<double>& grid,
                        const double* csh, const double* cns) {
@@ -1401,180 +1313,6 @@ void write_counts_file(const std::string& path, int B, int A, const std::vector<
     std::fprintf(f, "\n");
   }
   std::fclose(f);
-}
-
-int run_mut_pairs(const Options& opt) {
-  if (!opt.has("mut") || !opt.has("bins")) {
-    std::cerr << "Error: --pairs needs --mut and --bins (and optionally --chr, --num_bootstraps, --seed)." << std::endl;
-    return 1;
-  }
-  for (const char* o : {"target_mask", "reference_mask", "coal"})
-    if (opt.has(o)) {  // per-sample masks / one warm start cannot apply to a whole list of pairs: refuse, do not ignore
-      std::cerr << "Error: --" << o << " cannot be combined with --pairs (run such pairs one by one)." << std::endl;
-      return 1;
-    }
-  std::vector<PairSpec> pairs;
-  {
-    std::ifstream is(opt.get("pairs"));
-    if (!is) {
-      std::cerr << "Error while opening file " << opt.get("pairs") << std::endl;
-      return 1;
-    }
-    std::string line;
-    while (std::getline(is, line)) {
-      std::istringstream ss(line);
-      PairSpec ps;
-      if (!(ss >> ps.target >> ps.reference >> ps.output)) continue;
-      std::string a1, a2;
-      if (ss >> a1) ps.target_age = std::stof(a1);
-      if (ss >> a2) ps.ref_age = std::stof(a2);
-      pairs.push_back(ps);
-    }
-  }
-  if (pairs.empty()) {
-    std::cerr << "Error: no pairs in " << opt.get("pairs") << std::endl;
-    return 1;
-  }
-  std::cerr << "---------------------------------------------------------" << std::endl;
-  std::cerr << "Calculating coalescence rates for " << pairs.size() << " pairs of (ancient) samples.." << std::endl;
-  double years_per_gen = 28.0;
-  if (opt.has("years_per_gen")) years_per_gen = std::stof(opt.get("years_per_gen"));
-  const double C = 10;
-  std::vector<double> age_grid(256);
-  const int A = colate_age_grid(age_grid.data(), 256);
-  age_grid.resize(A);
-  const int num_bases_per_block = 30e6;
-  int seed = std::time(0) + getpid();
-  if (opt.has("seed")) seed = std::stoi(opt.get("seed"));
-  int B = 1;
-  if (opt.has("num_bootstraps")) B = std::stoi(opt.get("num_bootstraps"));
-  if (B < 1) {
-    std::cerr << "Error: --num_bootstraps must be at least 1." << std::endl;
-    return 1;
-  }
-  std::vector<std::string> mut_files, tmask, rmask, names;
-  if (opt.has("chr")) {
-    GzText is_chr;
-    if (!is_chr.open(opt.get("chr"))) std::cerr << "Error while opening file " << opt.get("chr") << std::endl;
-    std::string line;
-    while (is_chr.getline(line)) {
-      names.push_back(line);
-      mut_files.push_back(opt.get("mut") + "_chr" + line + ".mut");
-    }
-  } else {
-    names.push_back("");
-    mut_files.push_back(opt.get("mut"));
-  }
-
-  const size_t P = pairs.size();
-  std::map<std::string, std::vector<MutRow>> mut_cache;
-  std::vector<std::vector<double>> csh(P), cns(P), epochs(P);
-  std::vector<int> ep_null(P, 0);
-  std::vector<double> age(P);
-  for (size_t p = 0; p < P; p++) {
-    std::cerr << "Pair " << p + 1 << " / " << P << ": " << pairs[p].target << " x " << pairs[p].reference << std::endl;
-    age[p] = std::max(pairs[p].target_age, pairs[p].ref_age) / years_per_gen;
-    std::mt19937 rng;
-    rng.seed(seed);  // as an independent run of this pair would
-    BlockTables tab;
-    const int nb = fill_tables_from_tmp(names, mut_files, pairs[p].target, pairs[p].reference, tmask, rmask, C, rng,
-                                        num_bases_per_block, A, tab, &mut_cache);
-    std::cerr << "Number of blocks: " << nb << std::endl;
-    if (nb < 1) {
-      std::cerr << "Error: no genome blocks were read." << std::endl;
-      return 1;
-    }
-    std::vector<double> fsh((size_t)nb * A), fns((size_t)nb * A), fshe((size_t)nb * A), fnse((size_t)nb * A);
-    for (int j = 0; j < nb; j++) {
-      std::copy(tab.sh[j].begin(), tab.sh[j].end(), fsh.begin() + (size_t)j * A);
-      std::copy(tab.ns[j].begin(), tab.ns[j].end(), fns.begin() + (size_t)j * A);
-      std::copy(tab.sh_emp[j].begin(), tab.sh_emp[j].end(), fshe.begin() + (size_t)j * A);
-      std::copy(tab.ns_emp[j].begin(), tab.ns_emp[j].end(), fnse.begin() + (size_t)j * A);
-    }
-    csh[p].assign((size_t)B * A, 0.0);
-    cns[p].assign((size_t)B * A, 0.0);
-    if (int rc = colate_bootstrap_counts(&rng, B, nb, A, age_grid.data(), age[p], fsh.data(), fns.data(), fshe.data(),
-                                         fnse.data(), csh[p].data(), cns[p].data())) {
-      std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
-      return 1;
-    }
-    if (opt.has("counts_only") || opt.has("counts_out"))
-      write_counts_file(pairs[p].output + ".counts", B, A, age_grid, csh[p].data(), cns[p].data());
-    epochs[p].resize(COLATE_MAX_EPOCHS);
-    const int E = colate_epochs_from_bins(opt.get("bins").c_str(), age[p], years_per_gen, epochs[p].data(),
-                                          COLATE_MAX_EPOCHS, &ep_null[p]);
-    if (E <= 0) {
-      std::cerr << colate_last_error() << std::endl;
-      return 1;
-    }
-    epochs[p].resize(E);
-  }
-  if (opt.has("counts_only")) return 0;
-
-  std::cerr << "Maximising likelihood using EM.. " << std::endl;
-  if (opt.has("device")) {
-    if (int rc = colate_set_device(std::stoi(opt.get("device")))) {
-      std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
-      return 1;
-    }
-  }
-  std::vector<int> dev_list;
-  if (opt.has("devices")) {
-    const int nd = std::stoi(opt.get("devices"));
-    if (nd < 1) {
-      std::cerr << "Error: --devices must be at least 1." << std::endl;
-      return 1;
-    }
-    for (int d = 0; d < nd; d++) dev_list.push_back(d);
-  }
-  std::vector<bool> done(P, false);
-  for (size_t p0 = 0; p0 < P; p0++) {  // one launch per distinct number of epochs
-    if (done[p0]) continue;
-    const int E = (int)epochs[p0].size();
-    std::vector<size_t> grp;
-    for (size_t p = p0; p < P; p++)
-      if (!done[p] && (int)epochs[p].size() == E) grp.push_back(p);
-    const size_t R = grp.size() * (size_t)B;
-    std::vector<double> g_sh(R * A), g_ns(R * A), g_ep(R * E), g_init(R * E, COLATE_DEFAULT_INIT_RATE), g_rates(R * E), g_ll(R);
-    std::vector<int> g_it(R), g_fl(R);
-    for (size_t k = 0; k < grp.size(); k++) {
-      const size_t p = grp[k];
-      std::copy(csh[p].begin(), csh[p].end(), g_sh.begin() + k * B * A);
-      std::copy(cns[p].begin(), cns[p].end(), g_ns.begin() + k * B * A);
-      for (int i = 0; i < B; i++) std::copy(epochs[p].begin(), epochs[p].end(), g_ep.begin() + (k * B + i) * E);
-    }
-    int rc;
-    if (!dev_list.empty())  // --devices N: the rows (pairs x replicates) shard over GPUs 0..N-1
-      rc = colate_em_batch_rows_sharded((int)dev_list.size(), dev_list.data(), (int)R, E, A, age_grid.data(), g_sh.data(),
-                                        g_ns.data(), g_ep.data(), g_init.data(), COLATE_DEFAULT_MAX_ITER,
-                                        COLATE_DEFAULT_MIN_ITER, COLATE_DEFAULT_REL_TOL, COLATE_DEFAULT_RATE_FLOOR,
-                                        g_rates.data(), g_it.data(), g_ll.data(), g_fl.data());
-    else
-      rc = colate_em_batch_rows((int)R, E, A, age_grid.data(), g_sh.data(), g_ns.data(), g_ep.data(), g_init.data(),
-                                COLATE_DEFAULT_MAX_ITER, COLATE_DEFAULT_MIN_ITER, COLATE_DEFAULT_REL_TOL,
-                                COLATE_DEFAULT_RATE_FLOOR, g_rates.data(), g_it.data(), g_ll.data(), g_fl.data());
-    if (rc) {
-      std::cerr << "Error: " << colate_last_error() << " (" << rc << ")" << std::endl;
-      return 1;
-    }
-    for (size_t k = 0; k < grp.size(); k++) {
-      const size_t p = grp[k];
-      for (int i = 0; i < B; i++)
-        std::cerr << "Pair " << p + 1 << " Bootstrap " << i + 1 << ": Total iterations " << g_it[k * B + i] << std::endl;
-      if (colate_write_coal((pairs[p].output + ".coal").c_str(), B, E, epochs[p].data(), g_rates.data() + k * B * E,
-                            age[p] > 0.0 ? 1 : 0, ep_null[p])) {
-        std::cerr << "Error: " << colate_last_error() << std::endl;
-        return 1;
-      }
-      done[p] = true;
-    }
-  }
-  rusage usage;
-  getrusage(RUSAGE_SELF, &usage);
-  std::cerr << "CPU Time spent: " << usage.ru_utime.tv_sec << "." << std::setfill('0') << std::setw(6)
-            << usage.ru_utime.tv_usec << "s; Max Memory usage: " << usage.ru_maxrss / 1000.0 << "Mb." << std::endl;
-  std::cerr << "---------------------------------------------------------" << std::endl << std::endl;
-  return 0;
 }
 
 // ------------------------------------------------------------------ --mode make_tmp --target_table
@@ -1708,11 +1446,7 @@ int run_make_tmp(const Options& opt) {
     }
   }
   std::fclose(fp);
-  rusage usage;  // coal.cpp:3055-3067
-  getrusage(RUSAGE_SELF, &usage);
-  std::cerr << "CPU Time spent: " << usage.ru_utime.tv_sec << "." << std::setfill('0') << std::setw(6)
-            << usage.ru_utime.tv_usec << "s; Max Memory usage: " << usage.ru_maxrss / 1000.0 << "Mb." << std::endl;
-  std::cerr << "---------------------------------------------------------" << std::endl << std::endl;
+  print_usage_footer();  // coal.cpp:3055-3067
   return 0;
 }
 
@@ -1733,10 +1467,12 @@ int run_ranked(const Options& opt, int nranks) {
     std::cerr << "Error: --ranks needs --seed (every rank must draw the same bootstrap weights)." << std::endl;
     return 1;
   }
-  if (opt.has("pairs") || opt.has("devices")) {
-    std::cerr << "Error: --ranks cannot be combined with --pairs or --devices." << std::endl;
+  if (opt.has("devices")) {
+    std::cerr << "Error: --ranks cannot be combined with --devices." << std::endl;
     return 1;
   }
+  // where the ranks other than 0 keep their progress lines: next to the output (with --pairs: next to the list of pairs)
+  const std::string log_prefix = opt.has("pairs") ? opt.get("pairs") : opt.get("output");
   int up[2];
   if (::pipe(up) != 0) {
     std::perror("pipe");
@@ -1773,17 +1509,17 @@ int run_ranked(const Options& opt, int nranks) {
         ::close(up[1]);
         g_rank.fd_id_in = down_r[r];
         // only rank 0 talks on the terminal; the others keep their progress lines in a file that a clean exit removes
-        const std::string log = opt.get("output") + ".rank" + std::to_string(r) + ".stderr";
+        const std::string log = log_prefix + ".rank" + std::to_string(r) + ".stderr";
         if (!std::freopen(log.c_str(), "w", stderr)) std::perror("freopen");
       }
       int code = 1;
       try {
-        code = run_mut(opt);
+        code = opt.has("pairs") ? run_mut_pairs(opt) : run_mut(opt);
       } catch (const std::exception& e) {
         std::cerr << "Error: " << e.what() << std::endl;
       }
       std::cerr.flush();
-      if (r != 0 && code == 0) std::remove((opt.get("output") + ".rank" + std::to_string(r) + ".stderr").c_str());
+      if (r != 0 && code == 0) std::remove((log_prefix + ".rank" + std::to_string(r) + ".stderr").c_str());
       std::fflush(nullptr);
       ::_exit(code);
     }
@@ -1817,7 +1553,7 @@ int run_ranked(const Options& opt, int nranks) {
       const bool ok = (w == pids[r]) && WIFEXITED(st) && WEXITSTATUS(st) == 0;
       if (!ok) {
         std::cerr << "Error: rank " << r << (killed ? " was ended by the launcher" : " failed");
-        if (r > 0) std::cerr << " (see " << opt.get("output") << ".rank" << r << ".stderr)";
+        if (r > 0) std::cerr << " (see " << log_prefix << ".rank" << r << ".stderr)";
         std::cerr << std::endl;
         worst = 1;
         if (!failing) failing = true, t_fail = std::chrono::steady_clock::now();
@@ -1837,7 +1573,9 @@ int run_ranked(const Options& opt, int nranks) {
   return worst;
 }
 
-}  // namespace
+}  // namespace colate_drv
+
+using namespace colate_drv;
 
 extern "C" int colate_mut_main(int argc, char** argv) {
   Options opt;
@@ -1865,7 +1603,7 @@ extern "C" int colate_mut_main(int argc, char** argv) {
           std::cerr << "Error: --ranks must be between 1 and 64." << std::endl;
           return 1;
         }
-        if (opt.has("mut") && opt.has("output")) return run_ranked(opt, nranks);  // (also for N = 1: same code path)
+        if (opt.has("mut") && (opt.has("output") || opt.has("pairs"))) return run_ranked(opt, nranks);  // (also for N = 1: same code path)
       }
       if (opt.has("pairs")) return run_mut_pairs(opt);
       return run_mut(opt);

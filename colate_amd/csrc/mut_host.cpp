@@ -164,33 +164,24 @@ int colate_bootstrap_weights(void* rng_state, int num_bootstrap, int nb, double*
   return COLATE_OK;
 }
 
-// coal.cpp:3344-3451 for all replicates (the emp tables are reduced to the row the
-// reference reads: bin1 == 0, coal.cpp:3397)
-int colate_bootstrap_counts(void* rng_state, int num_bootstrap, int nb, int A,
-                            const double* age_grid, double age, const double* sh_block,
-                            const double* ns_block, const double* sh_emp_block,
-                            const double* ns_emp_block, double* cnt_shared,
-                            double* cnt_notshared) {
-  if (!rng_state || !age_grid || !sh_block || !ns_block || !sh_emp_block || !ns_emp_block ||
-      !cnt_shared || !cnt_notshared)
+// coal.cpp:3358-3451 for all replicates, from given block weights w[num_bootstrap][nb] (the emp tables are reduced to the
+// row the reference reads: bin1 == 0, coal.cpp:3397).  The host twin of bootstrap_kernel (bootstrap_kernel.hip).
+int colate_bootstrap_counts_from_weights(int num_bootstrap, int nb, int A, const double* age_grid, double age,
+                                         const double* weights, const double* sh_block, const double* ns_block,
+                                         const double* sh_emp_block, const double* ns_emp_block, double* cnt_shared,
+                                         double* cnt_notshared) {
+  if (!weights || !age_grid || !sh_block || !ns_block || !sh_emp_block || !ns_emp_block || !cnt_shared || !cnt_notshared)
     return fail(COLATE_EINVAL, "NULL argument");
   if (num_bootstrap < 1 || nb < 1 || A < 2) return fail(COLATE_EINVAL, "bad sizes");
-  std::mt19937& rng = *static_cast<std::mt19937*>(rng_state);
-  std::uniform_int_distribution<int> dist_blocks(0, nb - 1);
-  std::vector<double> blocks(nb), sh_emp(A), ns_emp(A), F(A);
+  std::vector<double> sh_emp(A), ns_emp(A), F(A);
   for (int i = 0; i < num_bootstrap; i++) {
+    const double* blocks = weights + (size_t)i * nb;
     double* csh = cnt_shared + (size_t)i * A;
     double* cns = cnt_notshared + (size_t)i * A;
     std::fill(csh, csh + A, 0.0);
     std::fill(cns, cns + A, 0.0);
     std::fill(sh_emp.begin(), sh_emp.end(), 0.0);
     std::fill(ns_emp.begin(), ns_emp.end(), 0.0);
-    if (num_bootstrap == 1) {
-      std::fill(blocks.begin(), blocks.end(), 1.0);
-    } else {
-      std::fill(blocks.begin(), blocks.end(), 0.0);
-      for (int j = 0; j < nb; j++) blocks[dist_blocks(rng)] += 1.0;
-    }
     for (int j = 0; j < nb; j++) {
       if (blocks[j] > 0.0) {
         const double w = blocks[j];
@@ -229,6 +220,21 @@ int colate_bootstrap_counts(void* rng_state, int num_bootstrap, int nb, int A,
     }
   }
   return COLATE_OK;
+}
+
+// coal.cpp:3344-3451 for all replicates: the weights of replicate i are drawn right before its sums, as the reference
+// does -- the generator is shared with nothing else at this point, so drawing them all first is the same stream
+int colate_bootstrap_counts(void* rng_state, int num_bootstrap, int nb, int A,
+                            const double* age_grid, double age, const double* sh_block,
+                            const double* ns_block, const double* sh_emp_block,
+                            const double* ns_emp_block, double* cnt_shared,
+                            double* cnt_notshared) {
+  if (!rng_state) return fail(COLATE_EINVAL, "NULL argument");
+  if (num_bootstrap < 1 || nb < 1 || A < 2) return fail(COLATE_EINVAL, "bad sizes");
+  std::vector<double> weights((size_t)num_bootstrap * nb);
+  if (int rc = colate_bootstrap_weights(rng_state, num_bootstrap, nb, weights.data())) return rc;
+  return colate_bootstrap_counts_from_weights(num_bootstrap, nb, A, age_grid, age, weights.data(), sh_block, ns_block,
+                                              sh_emp_block, ns_emp_block, cnt_shared, cnt_notshared);
 }
 
 // coal.cpp:3660-3672 and 3830-3847.  operator<<(double) with default flags is "%g".

@@ -46,7 +46,19 @@ int colate_em_batch_rows_sharded(int, const int*, int, int, int, const double*, 
 int colate_bootstrap_em_batch(int, int, int, int, const double*, double, const double*, const double*, const double*,
                               const double*, const double*, const double*, const double*, int, int, double, double, double*,
                               int*, double*, int*, double*, double*) { return nodev(); }
-int colate_shard_bounds(int, int, int, int*, int*) { return nodev(); }
+int colate_shard_bounds(int B, int nranks, int rank, int* lo, int* hi) {
+  const int base = B / nranks, rem = B % nranks;
+  *lo = rank * base + (rank < rem ? rank : rem);
+  *hi = *lo + base + (rank < rem ? 1 : 0);
+  return COLATE_OK;
+}
+int colate_bootstrap_em_batch_groups(int, int, int, int, const double*, const int*, const double*, const double*, const double*,
+                                     const double*, const double*, const double*, const double*, const double*, int, int, double,
+                                     double, double*, int*, double*, int*, double*, double*) { return nodev(); }
+int colate_bootstrap_em_batch_groups_allgather(void*, int, int, int, int, int, int, const double*, const int*, const double*,
+                                               const double*, const double*, const double*, const double*, const double*,
+                                               const double*, const double*, int, int, double, double, double*, int*, double*,
+                                               int*) { return nodev(); }
 int colate_comm_unique_id(void*) { return nodev(); }
 int colate_comm_create(const void*, int, int, void**) { return nodev(); }
 int colate_comm_destroy(void*) { return COLATE_OK; }

@@ -187,6 +187,14 @@ int colate_bootstrap_counts(void* rng_state, int num_bootstrap, int nb, int A,
  * num_bootstrap == 1), drawn from the same std::mt19937 -- the host half of the GPU bootstrap below. */
 int colate_bootstrap_weights(void* rng_state, int num_bootstrap, int nb, double* weights);
 
+/* coal.cpp:3358-3451 alone, on the host, from weights drawn before (colate_bootstrap_weights): the weighted block sums
+ * and the F redistribution.  colate_bootstrap_counts = colate_bootstrap_weights + this.  The host twin of the GPU
+ * bootstrap below (bit-identical); what `--counts_only` runs, which needs no device. */
+int colate_bootstrap_counts_from_weights(int num_bootstrap, int nb, int A, const double* age_grid, double age,
+                                         const double* weights, const double* sh_block, const double* ns_block,
+                                         const double* sh_emp_block, const double* ns_emp_block, double* cnt_shared,
+                                         double* cnt_notshared);
+
 /* coal.cpp:3358-3441 on the GPU: weighted block sums + F redistribution for B replicates, all
  * pointers in device memory (tables [nb][A], weights [B][nb], cnt_* [B][A]), asynchronous on
  * hip_stream; results are bit-identical to colate_bootstrap_counts.  `status` (device int, may be
@@ -209,6 +217,34 @@ int colate_bootstrap_em_batch(int B, int nb, int E, int A, const double* age_gri
                               int min_iter, double rel_tol, double rate_floor, double* out_rates,
                               int* out_iters, double* out_loglik, int* out_flags,
                               double* out_cnt_shared, double* out_cnt_notshared);
+
+/* ---- batched all-pairs (BASELINE configs[4]) --------------------------------------------
+ * The reference is run once per (target, reference) pair (coal.cpp:2071-2321 + 3071-3863 each time).  Here G pairs
+ * ("groups") go through ONE bootstrap launch and ONE EM launch: group g has its own genome-block tables (group_nb[g]
+ * blocks; the four tables of all groups are concatenated in group order, [sum_g nb_g][A]), its own sample age, its own
+ * epochs[g][E] / init_rates[g][E] (an ancient sample inserts its age as an epoch, coal.cpp:3597-3624; all groups of a
+ * call have the same E) and B bootstrap replicates with weights [B][nb_g], concatenated in group order as well.
+ * Row r = g * B + i of every output is replicate i of group g; results are bit-identical to G separate
+ * colate_bootstrap_em_batch calls.  out_cnt_* ([G*B][A], may be NULL) receive the count tables. */
+int colate_bootstrap_em_batch_groups(int G, int B, int E, int A, const double* age_grid, const int* group_nb,
+                                     const double* group_age, const double* weights, const double* sh_block,
+                                     const double* ns_block, const double* sh_emp_block,
+                                     const double* ns_emp_block, const double* epochs, const double* init_rates,
+                                     int max_iter, int min_iter, double rel_tol, double rate_floor,
+                                     double* out_rates, int* out_iters, double* out_loglik, int* out_flags,
+                                     double* out_cnt_shared, double* out_cnt_notshared);
+/* The bootstrap of rows [row_lo, row_hi) of such a batch, all pointers in device memory, asynchronous on hip_stream.
+ * The group arrays describe groups [group_first, group_first + G) (every row must belong to one of them):
+ * group_block_off[g] = number of genome blocks in front of group g in the tables given, group_weight_off[g] = number
+ * of weights in front of its [B][nb_g] weights; cnt_*[row_hi - row_lo][A]; `status` (device int, required) receives 1
+ * if a sample age lies outside the age grid. */
+int colate_bootstrap_counts_groups_device(int G, int B, int group_first, int row_lo, int row_hi, int A,
+                                          const double* age_grid, const int* group_nb,
+                                          const long long* group_block_off, const long long* group_weight_off,
+                                          const double* group_age, const double* weights, const double* sh_block,
+                                          const double* ns_block, const double* sh_emp_block,
+                                          const double* ns_emp_block, double* cnt_shared, double* cnt_notshared,
+                                          int* status, void* hip_stream);
 
 /* The host-pointer entry points above keep one device buffer, one pinned staging buffer and one stream per calling
  * thread between calls (grown on demand); this frees them. */
@@ -243,6 +279,19 @@ int colate_bootstrap_em_batch_allgather(void* comm, int B, int nb, int E, int A,
                                         const double* init_rates, int max_iter, int min_iter, double rel_tol,
                                         double rate_floor, double* out_rates, int* out_iters, double* out_loglik,
                                         int* out_flags);
+
+/* colate_bootstrap_em_batch_groups over the communicator: the G * B rows are sharded like replicates
+ * (colate_shard_bounds(G * B, nranks, rank)); a rank passes the arrays of the groups its rows belong to ONLY --
+ * groups [group_first, group_first + group_count) with group_first = lo / B, group_count = (hi - 1) / B - lo / B + 1 --
+ * so that it needs to read and fill the tables of those pairs alone; a rank without rows passes group_count = 0.
+ * Every rank receives all G * B results.  `Colate --pairs FILE --ranks N` is the command-line form. */
+int colate_bootstrap_em_batch_groups_allgather(void* comm, int G, int B, int group_first, int group_count, int E, int A,
+                                               const double* age_grid, const int* group_nb, const double* group_age,
+                                               const double* weights, const double* sh_block, const double* ns_block,
+                                               const double* sh_emp_block, const double* ns_emp_block,
+                                               const double* epochs, const double* init_rates, int max_iter,
+                                               int min_iter, double rel_tol, double rate_floor, double* out_rates,
+                                               int* out_iters, double* out_loglik, int* out_flags);
 
 /* coal.cpp:3660-3672, 3830-3847: the .coal text (6 significant digits, trailing blank). */
 int colate_write_coal(const char* path, int B, int E, const double* epochs, const double* rates,

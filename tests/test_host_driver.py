@@ -139,8 +139,8 @@ def test_write_coal_format(ca, tmp_path):
     assert np.array_equal(r2, np.array([float("%g" % x) for x in rates[0]]))
 
 
-def _run_cli(args, cwd):
-    return subprocess.run([CLI] + args, cwd=cwd, capture_output=True)
+def _run_cli(args, cwd, env=None):
+    return subprocess.run([CLI] + args, cwd=cwd, capture_output=True, env=env)
 
 
 @pytest.mark.parametrize("name", gl.l3_names())
@@ -201,9 +201,10 @@ def test_pairs_mode_counts_equal_separate_runs(tmp_path):
     common = ["--mode", "mut", "--mut", "P", "--chr", "chr.txt", "--bins", "3,7,0.2", "--seed", "5", "--num_bootstraps", "2"]
     specs = [("T.colate.in", "R.colate.in", "ab", "7000", "0"), ("R.colate.in", "T.colate.in", "ba", "0", "0")]
     (tmp_path / "pairs.txt").write_text("".join(" ".join(sp) + "\n" for sp in specs))
-    r = _run_cli(common + ["--pairs", "pairs.txt", "--counts_only"], str(tmp_path))
+    r = _run_cli(common + ["--pairs", "pairs.txt", "--counts_only"], str(tmp_path), env=dict(os.environ, COLATE_TIMING="1"))
     assert r.returncode == 0, r.stderr.decode()[-800:]
-    assert r.stderr.decode().count("parsing CHR: 1 / 3") == 2
+    # every input file is read once, whatever number of pairs it takes part in (here: both files in both pairs)
+    assert "3 .mut files" in r.stderr.decode() and "2 .colate.in files" in r.stderr.decode(), r.stderr.decode()[-800:]
     for tgt, ref, out, ta, ra in specs:
         r = _run_cli(common + ["--target_tmp", tgt, "--reference_tmp", ref, "--target_age", ta, "--reference_age", ra,
                                "-o", out + "_single", "--counts_out", out + "_single.counts", "--counts_only"], str(tmp_path))

@@ -1,7 +1,10 @@
 // tools/gen_wg_inputs.cpp -- TEST / BENCH INFRASTRUCTURE: synthetic `Colate --mode mut` inputs at realistic size, fast.
 // Same shape as tests/synth_files.py (the formats of include/src/mutations.cpp:77-246 and include/coal/coal.cpp:2505-2514):
 // per chromosome P_chr<c>.mut(.gz), plus T.colate.in, R.colate.in and chr.txt in <outdir>.
-//   g++ -O2 -std=c++17 tools/gen_wg_inputs.cpp -lz -o /tmp/gen_wg_inputs && /tmp/gen_wg_inputs OUT 22 1000000 [gz]
+//   g++ -O2 -std=c++17 tools/gen_wg_inputs.cpp -lz -o /tmp/gen_wg_inputs && /tmp/gen_wg_inputs OUT 22 1000000 [gz|plain [NT NR]]
+// With NT / NR (BASELINE configs[4]: 10 x 10): additionally T1..T<NT-1>.colate.in and R1..R<NR-1>.colate.in, further samples
+// over the same .mut files (each from a generator of its own, so T.colate.in / R.colate.in = sample 0 do not depend on
+// NT / NR), and pairs.txt listing all NT x NR pairs as `T<i>.colate.in R<j>.colate.in out_<i>_<j>`.
 #include <zlib.h>
 
 #include <algorithm>
@@ -29,10 +32,23 @@ int main(int argc, char** argv) {
   const std::string out = argv[1];
   const int nchr = atoi(argv[2]), snps = atoi(argv[3]);
   const bool gz = argc > 4 && !strcmp(argv[4], "gz");
+  const int NT = argc > 6 ? atoi(argv[5]) : 1, NR = argc > 6 ? atoi(argv[6]) : 1;
   std::mt19937_64 rng(12345);
   std::uniform_real_distribution<double> U(0, 1);
   FILE* tgt = fopen((out + "/T.colate.in").c_str(), "wb");
   FILE* ref = fopen((out + "/R.colate.in").c_str(), "wb");
+  // further samples: own files, own generators; their coverage and sharing differ a little from sample to sample
+  std::vector<FILE*> xt, xr;
+  std::vector<std::mt19937_64> gt, gr;
+  for (int k = 1; k < NT; k++) xt.push_back(fopen((out + "/T" + std::to_string(k) + ".colate.in").c_str(), "wb")), gt.emplace_back(1000 + k);
+  for (int k = 1; k < NR; k++) xr.push_back(fopen((out + "/R" + std::to_string(k) + ".colate.in").c_str(), "wb")), gr.emplace_back(2000 + k);
+  if (NT > 1 || NR > 1) {
+    FILE* pf = fopen((out + "/pairs.txt").c_str(), "w");
+    for (int i = 0; i < NT; i++)
+      for (int j = 0; j < NR; j++)
+        fprintf(pf, "T%s.colate.in R%s.colate.in out_%d_%d\n", i ? std::to_string(i).c_str() : "", j ? std::to_string(j).c_str() : "", i, j);
+    fclose(pf);
+  }
   FILE* chrf = fopen((out + "/chr.txt").c_str(), "w");
   const char bases[] = "ACGT";
   const long span = 240000000;
@@ -85,10 +101,31 @@ int main(int argc, char** argv) {
         int daf = U(rng) > 0.05 ? (shares ? nr : 0) : (nr ? (int)(U(rng) * (nr + 1)) % (nr + 1) : 0);
         rec(tgt, name, bp, a, d, nr - daf, daf);
       }
+      for (size_t k = 0; k < xr.size(); k++) {  // further reference samples
+        std::mt19937_64& g = gr[k];
+        if (U(g) < 0.88 + 0.01 * k) {
+          const int daf = (int)(U(g) * 3) % 3;
+          const bool sw = U(g) < 0.03;
+          rec(xr[k], name, bp, sw ? d : a, sw ? a : d, 2 - daf, daf);
+        }
+        if (U(g) < 0.1) rec(xr[k], name, bp + 1, 'A', 'G', 1, 1);
+      }
+      for (size_t k = 0; k < xt.size(); k++) {  // further targets: own coverage, own pairwise Ne
+        std::mt19937_64& g = gt[k];
+        if (U(g) < 0.6 + 0.03 * k) {
+          const int nr = (int)(U(g) * 5) % 5;
+          const double age_mid = 0.5 * (age_begin + age_end);
+          const bool shares = U(g) < 0.8 * (1.0 - std::exp(-age_mid / (8000.0 + 1500.0 * k)));
+          int daf = U(g) > 0.05 ? (shares ? nr : 0) : (nr ? (int)(U(g) * (nr + 1)) % (nr + 1) : 0);
+          rec(xt[k], name, bp, a, d, nr - daf, daf);
+        }
+      }
     }
     put(buf);
     if (gz) gzclose(gf); else fclose(pf);
   }
   fclose(tgt); fclose(ref); fclose(chrf);
+  for (FILE* f : xt) fclose(f);
+  for (FILE* f : xr) fclose(f);
   return 0;
 }
