@@ -23,6 +23,9 @@ from .api import (  # noqa: F401
     age_grid,
     bootstrap_counts,
     bootstrap_counts_device,
+    bootstrap_counts_from_weights,
+    bootstrap_em_batch,
+    bootstrap_em_batch_groups,
     bootstrap_weights,
     coal_EM,
     device_count,

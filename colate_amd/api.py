@@ -127,6 +127,67 @@ def bootstrap_counts_device(age_grid_, age, weights, sh_block, ns_block, sh_emp_
     return status
 
 
+def bootstrap_counts_from_weights(age_grid_, age, weights, sh_block, ns_block, sh_emp_block, ns_emp_block):
+    """coal.cpp:3358-3451 on the host from given weights[B][nb] (the host twin of the GPU bootstrap)."""
+    g, w = _f64(age_grid_), _f64(np.atleast_2d(weights))
+    t = [_f64(x) for x in (sh_block, ns_block, sh_emp_block, ns_emp_block)]
+    nb, A = t[0].shape
+    B = w.shape[0]
+    assert w.shape == (B, nb)
+    csh = np.zeros((B, A))
+    cns = np.zeros((B, A))
+    check(lib.colate_bootstrap_counts_from_weights(B, nb, A, _p(g), float(age), _p(w), _p(t[0]), _p(t[1]), _p(t[2]), _p(t[3]),
+                                                   _p(csh), _p(cns)))
+    return csh, cns
+
+
+def bootstrap_em_batch(age_grid_, age, weights, sh_block, ns_block, sh_emp_block, ns_emp_block, epochs, init_rates=None,
+                       max_iter=DEFAULT_MAX_ITER, min_iter=DEFAULT_MIN_ITER, rel_tol=DEFAULT_REL_TOL,
+                       rate_floor=DEFAULT_RATE_FLOOR, want_counts=False):
+    """colate_bootstrap_em_batch: block tables [nb][A] + weights [B][nb] -> (rates, iters, loglik, flags[, csh, cns])."""
+    g, w, ep = _f64(age_grid_), _f64(np.atleast_2d(weights)), _f64(epochs)
+    t = [_f64(x) for x in (sh_block, ns_block, sh_emp_block, ns_emp_block)]
+    nb, A = t[0].shape
+    B, E = w.shape[0], ep.size
+    init = _f64(np.full(E, DEFAULT_INIT_RATE) if init_rates is None else init_rates)
+    rates, iters, ll, flags = np.zeros((B, E)), np.zeros(B, dtype=np.int32), np.zeros(B), np.zeros(B, dtype=np.int32)
+    csh, cns = (np.zeros((B, A)), np.zeros((B, A))) if want_counts else (None, None)
+    check(lib.colate_bootstrap_em_batch(B, nb, E, A, _p(g), float(age), _p(w), _p(t[0]), _p(t[1]), _p(t[2]), _p(t[3]), _p(ep),
+                                        _p(init), max_iter, min_iter, rel_tol, rate_floor, _p(rates), _p(iters), _p(ll),
+                                        _p(flags), _p(csh) if want_counts else None, _p(cns) if want_counts else None))
+    return (rates, iters, ll, flags, csh, cns) if want_counts else (rates, iters, ll, flags)
+
+
+def bootstrap_em_batch_groups(age_grid_, ages, weights, tables, epochs, init_rates=None, max_iter=DEFAULT_MAX_ITER,
+                              min_iter=DEFAULT_MIN_ITER, rel_tol=DEFAULT_REL_TOL, rate_floor=DEFAULT_RATE_FLOOR,
+                              want_counts=False):
+    """colate_bootstrap_em_batch_groups (batched all-pairs): per group g a sample age ages[g], weights[g] = [B][nb_g],
+    tables[g] = (sh, ns, sh_emp, ns_emp) each [nb_g][A], epochs[g] = [E].  Row g * B + i of the outputs = replicate i
+    of group g."""
+    g = _f64(age_grid_)
+    G = len(weights)
+    ws = [_f64(np.atleast_2d(w)) for w in weights]
+    B = ws[0].shape[0]
+    nb = np.ascontiguousarray([w.shape[1] for w in ws], dtype=np.int32)
+    assert all(w.shape[0] == B for w in ws)
+    ep = _f64(np.atleast_2d(epochs))
+    E, A = ep.shape[1], g.size
+    assert ep.shape == (G, E)
+    init = _f64(np.full((G, E), DEFAULT_INIT_RATE) if init_rates is None else np.atleast_2d(init_rates))
+    w_all = _f64(np.concatenate([w.ravel() for w in ws]))
+    t_all = [_f64(np.concatenate([_f64(tables[k][j]).reshape(-1, A) for k in range(G)])) for j in range(4)]
+    assert all(t.shape == (int(nb.sum()), A) for t in t_all)
+    a = _f64(ages)
+    R = G * B
+    rates, iters, ll, flags = np.zeros((R, E)), np.zeros(R, dtype=np.int32), np.zeros(R), np.zeros(R, dtype=np.int32)
+    csh, cns = (np.zeros((R, A)), np.zeros((R, A))) if want_counts else (None, None)
+    check(lib.colate_bootstrap_em_batch_groups(G, B, E, A, _p(g), _p(nb), _p(a), _p(w_all), _p(t_all[0]), _p(t_all[1]),
+                                               _p(t_all[2]), _p(t_all[3]), _p(ep), _p(init), max_iter, min_iter, rel_tol,
+                                               rate_floor, _p(rates), _p(iters), _p(ll), _p(flags),
+                                               _p(csh) if want_counts else None, _p(cns) if want_counts else None))
+    return (rates, iters, ll, flags, csh, cns) if want_counts else (rates, iters, ll, flags)
+
+
 def write_coal(path, epochs, rates, is_ancient=False, ep_null=0):
     e = _f64(epochs)
     r = _f64(np.atleast_2d(rates))

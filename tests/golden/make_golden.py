@@ -9,6 +9,7 @@ shim; Colate_ref = its `Colate` CLI) and this script records inputs + outputs:
                     (epochs, rates, age): logl, num[E], denom[E] as hex floats (bit-exact)
   l2_em_*.json      count tables -> `Colate_ref --mode mut` through its .colate_mat hook
                     (coal.cpp:3169-3170, 3471-3499): .coal text and "Total iterations" per replicate
+  l3_pairs/         four samples over one set of .mut files, the reference CLI run once per (target, reference) pair
   l3_*/             synthetic .mut(.gz) + .colate.in + chr.txt inputs (tests/synth_files.py) and the
                     .coal the reference CLI writes for them with --seed (full path: readers, age
                     sampling, block bootstrap, F redistribution, epochs, EM, writer)
@@ -200,6 +201,37 @@ def make_l3():
         print(f"{name}: blocks={nblocks} iterations={iters}")
 
 
+def make_l3_pairs():
+    """Batched all-pairs (BASELINE configs[4]): the reference is run ONCE PER PAIR -- it has no
+    list mode -- on samples that share one set of .mut files, every run with the same --seed; the fixture holds each
+    pair's .coal and iteration counts.  `Colate --pairs` of this repo must write exactly these files.  Two of the pairs have
+    an ancient sample: 500 years (one more epoch than the others, coal.cpp:3597-3624: a second launch) and 7000 years
+    (same number of epochs, the ancient .coal layout)."""
+    d = os.path.join(HERE, "l3_pairs")
+    shutil.rmtree(d, ignore_errors=True)
+    gen = dict(chroms=("1", "2", "3"), snps_per_chr=700, seed=41, gz=True, extra_targets=1, extra_refs=1)
+    synth_files.write_inputs(d, **gen)
+    common = ["--bins", "3,7,0.2", "--seed", "11", "--num_bootstraps", "3", "--chr", "chr.txt"]
+    pairs = [("T.colate.in", "R.colate.in", "p0", "0", "0"), ("T1.colate.in", "R.colate.in", "p1", "500", "0"),
+             ("T.colate.in", "R1.colate.in", "p2", "0", "0"), ("T1.colate.in", "R1.colate.in", "p3", "7000", "0"),
+             ("R.colate.in", "T.colate.in", "p4", "0", "0"), ("R1.colate.in", "T1.colate.in", "p5", "0", "500")]
+    meta = {"generator": "tests/golden/make_golden.py (oracle/_ref/Colate_ref, one run per pair)", "common_args": common, "pairs": []}
+    for tgt, ref, out, ta, ra in pairs:
+        args = ["--mode", "mut", "--mut", "P", "--target_tmp", tgt, "--reference_tmp", ref, "--target_age", ta, "--reference_age", ra] \
+            + common + ["-o", "expected_" + out]
+        err, iters = run_ref(args, d)
+        nblocks = int(re.search(r"Number of blocks: (\d+)", err).group(1))
+        meta["pairs"].append({"target": tgt, "reference": ref, "output": out, "target_age": ta, "reference_age": ra,
+                              "iterations": iters, "num_blocks": nblocks})
+        print(f"l3_pairs {out}: blocks={nblocks} iterations={iters}")
+    json.dump(meta, open(os.path.join(d, "case.json"), "w"))
+    for fn in sorted(os.listdir(d)):  # keep the fixtures small
+        if fn.endswith(".colate.in"):
+            with open(os.path.join(d, fn), "rb") as f, gzip.GzipFile(os.path.join(d, fn + ".gz"), "wb", mtime=0) as g:
+                g.write(f.read())
+            os.remove(os.path.join(d, fn))
+
+
 def _isnum(t):
     try:
         float(t)
@@ -289,4 +321,5 @@ if __name__ == "__main__":
     make_l1()
     make_l2()
     make_l3()
+    make_l3_pairs()
     make_l4()

@@ -40,7 +40,26 @@ def l2_case(name):
 
 
 def l3_names():
-    return sorted(f for f in os.listdir(HERE) if f.startswith("l3_"))
+    return sorted(f for f in os.listdir(HERE) if f.startswith("l3_") and f != "l3_pairs")
+
+
+def l3_pairs_stage(dst):
+    """The batched all-pairs fixture (l3_pairs: the reference run once per pair): copies the inputs and the expected
+    .coal files into `dst`, writes pairs.txt (`target reference output target_age reference_age` per line) and returns
+    the case description."""
+    src = os.path.join(HERE, "l3_pairs")
+    os.makedirs(dst, exist_ok=True)
+    for f in os.listdir(src):
+        if f.endswith(".colate.in.gz"):
+            with gzip.open(os.path.join(src, f), "rb") as g, open(os.path.join(dst, f[:-3]), "wb") as o:
+                o.write(g.read())
+        else:
+            shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+    meta = json.load(open(os.path.join(src, "case.json")))
+    with open(os.path.join(dst, "pairs.txt"), "w") as f:
+        for p in meta["pairs"]:
+            f.write(f"{p['target']} {p['reference']} {p['output']} {p['target_age']} {p['reference_age']}\n")
+    return meta
 
 
 def l3_stage(name, dst):

@@ -14,9 +14,15 @@ import numpy as np
 
 
 def write_inputs(outdir, chroms=("1", "2"), snps_per_chr=1500, seed=7, span=95_000_000, gz=False,
-                 with_chr_file=True):
+                 with_chr_file=True, extra_targets=0, extra_refs=0):
+    """extra_targets / extra_refs: further samples over the same .mut files (T1.colate.in, ..., R1.colate.in, ...), each drawn
+    from a generator of its own so that T.colate.in / R.colate.in do not depend on them (batched all-pairs fixtures)."""
     rng = np.random.default_rng(seed)
     os.makedirs(outdir, exist_ok=True)
+    xt = [(open(os.path.join(outdir, f"T{k + 1}.colate.in"), "wb"), np.random.default_rng(seed * 1000 + 1 + k))
+          for k in range(extra_targets)]
+    xr = [(open(os.path.join(outdir, f"R{k + 1}.colate.in"), "wb"), np.random.default_rng(seed * 1000 + 501 + k))
+          for k in range(extra_refs)]
     bases = "ACGT"
     tgt = open(os.path.join(outdir, "T.colate.in"), "wb")
     ref = open(os.path.join(outdir, "R.colate.in"), "wb")
@@ -66,8 +72,24 @@ def write_inputs(outdir, chroms=("1", "2"), snps_per_chr=1500, seed=7, span=95_0
                     shares = rng.uniform() < 0.8 * (1.0 - np.exp(-age_mid / 12000.0))
                     daf = (n if shares else 0) if rng.uniform() > 0.05 else (int(rng.integers(0, n + 1)) if n else 0)
                     rec(tgt, name, int(bp), a, d, n - daf, daf)
+                for k, (f2, g2) in enumerate(xr):  # further reference samples
+                    if g2.uniform() < 0.85:
+                        daf = int(g2.integers(0, 3))
+                        ra, rd = (a, d) if g2.uniform() > 0.03 else (d, a)
+                        rec(f2, name, int(bp), ra, rd, 2 - daf, daf)
+                    if g2.uniform() < 0.1:
+                        rec(f2, name, int(bp) + 1, "A", "G", 1, 1)
+                for k, (f2, g2) in enumerate(xt):  # further targets: own coverage, own pairwise Ne
+                    if g2.uniform() < 0.8:
+                        n = int(g2.integers(0, 5))
+                        age_mid = 0.5 * (age_begin + age_end)
+                        shares = g2.uniform() < 0.8 * (1.0 - np.exp(-age_mid / (7000.0 + 3000.0 * k)))
+                        daf = (n if shares else 0) if g2.uniform() > 0.05 else (int(g2.integers(0, n + 1)) if n else 0)
+                        rec(f2, name, int(bp), a, d, n - daf, daf)
     tgt.close()
     ref.close()
+    for f2, _ in xt + xr:
+        f2.close()
     if with_chr_file:
         with open(os.path.join(outdir, "chr.txt"), "w") as f:
             for c in chroms:

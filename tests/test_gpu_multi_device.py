@@ -71,6 +71,30 @@ def test_cli_two_gpus_equal_one(ca, how, tmp_path):
     assert pick(two.stderr) == pick(one.stderr) and len(pick(one.stderr)) == len(case["iterations"])
 
 
+@pytest.mark.parametrize("nranks", [1, 2, 3])
+def test_pairs_with_ranks_equal_one_process(ca, nranks, tmp_path):
+    """`Colate --pairs FILE --ranks N` (BASELINE configs[4] on N GPUs): the (pair, replicate) rows of every launch are
+    sharded over N processes, each rank reads and fills only the pairs its rows belong to, one RCCL all-gather per launch;
+    the .coal files and the iteration lines are those of the one-process run.  N = 1 runs on any box (the same code with a
+    communicator of one); N = 2, 3 need as many visible GPUs (3 ranks over 6 pairs x 3 replicates cut inside pairs)."""
+    if nranks > 1 and ca.device_count() < nranks:
+        pytest.skip(f"needs {nranks} visible GPUs (runs on the multi-GPU node)")
+    meta = gl.l3_pairs_stage(str(tmp_path))
+    common = ["--mode", "mut", "--mut", "P"] + meta["common_args"] + ["--pairs", "pairs.txt"]
+    one = _run(common, tmp_path)
+    assert one.returncode == 0, one.stderr[-800:]
+    outs = [p["output"] for p in meta["pairs"]]
+    texts = {o: (tmp_path / (o + ".coal")).read_text() for o in outs}
+    for o in outs:
+        os.remove(tmp_path / (o + ".coal"))
+    many = _run(common + ["--ranks", str(nranks)], tmp_path)
+    assert many.returncode == 0, many.stderr[-800:]
+    for o in outs:
+        assert (tmp_path / (o + ".coal")).read_text() == texts[o], o
+    pick = lambda err: [l for l in err.split("\n") if " Bootstrap " in l]
+    assert pick(many.stderr) == pick(one.stderr) and len(pick(one.stderr)) == sum(len(p["iterations"]) for p in meta["pairs"])
+
+
 def test_two_ranks_one_fails_nobody_hangs(ca, tmp_path):
     """Rank 1's local work fails (injected): it still joins the all-gather with its code, rank 0 learns of it from the
     gathered codes, both exit non-zero and the launcher returns promptly."""

@@ -212,6 +212,25 @@ def test_pairs_mode_counts_equal_separate_runs(tmp_path):
         assert (tmp_path / (out + ".counts")).read_text() == (tmp_path / (out + "_single.counts")).read_text()
 
 
+def test_pairs_fixture_counts_reproduce_reference(tmp_path):
+    """`--pairs` against the REFERENCE (fixture l3_pairs: Colate_ref run once per pair, same --seed): the count tables of
+    every pair, through the oracle's EM, print exactly the .coal the reference wrote for that pair, with its iteration
+    counts -- modern pairs, a 500-year-old target (one epoch more: a launch of its own) and a 7000-year-old one."""
+    meta = gl.l3_pairs_stage(str(tmp_path))
+    common = ["--mode", "mut", "--mut", "P"] + meta["common_args"]
+    B = int(common[common.index("--num_bootstraps") + 1])
+    r = _run_cli(common + ["--pairs", "pairs.txt", "--counts_only"], str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    for p in meta["pairs"]:
+        assert f"{p['target']} x {p['reference']}: Number of blocks: {p['num_blocks']}" in r.stderr.decode()
+        grid, csh, cns = gl.read_counts(tmp_path / (p["output"] + ".counts"), B)
+        age = max(float(np.float32(p["target_age"])), float(np.float32(p["reference_age"]))) / 28.0
+        ep, ep_null = ol.epochs_from_bins(common[common.index("--bins") + 1], age, 28.0)
+        rates, iters, ll, fl = ol.em_batch(grid, csh, cns, ep)
+        assert iters.tolist() == p["iterations"], p["output"]
+        assert gl.coal_text(ep, rates, age > 0, ep_null) == (tmp_path / f"expected_{p['output']}.coal").read_text(), p["output"]
+
+
 def test_masks_change_the_tables(tmp_path):
     """The mask fixture really exercises the mask branch (coal.cpp:2169-2174): without the two masks the same
     inputs give different count tables."""
