@@ -150,9 +150,11 @@ int run_and_gather(Comm* c, int B, int E, double* out_rates, int* out_iters, dou
     const hipError_t e = hipMemsetAsync(c->d_send, 0, per_rank, c->stream);
     if (e != hipSuccess) local_rc = fail(COLATE_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
   }
-  if (const char* inj = getenv("COLATE_TEST_FAIL_RANK")) {  // failure injection for the tests of exactly this path
+#ifdef COLATE_TEST_HOOKS  // (only in lib/testhooks/libcolate_amd.so: failure injection for the tests of exactly this path)
+  if (const char* inj = getenv("COLATE_TEST_FAIL_RANK")) {
     if (atoi(inj) == c->rank) local_rc = fail(COLATE_EHIP, "injected failure on rank %d (COLATE_TEST_FAIL_RANK)", c->rank);
   }
+#endif
   if (!local_rc && hi > lo) {
     colate::ProfRange range("colate shard: bootstrap + EM on this rank's replicates");
     local_rc = local(hi - lo, lo, d_rates, d_ll, d_iters, d_flags, c->stream);

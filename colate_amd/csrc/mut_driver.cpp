@@ -8,6 +8,8 @@
 //
 // Everything here runs once per invocation on the host; the per-replicate EM,
 // which is where the reference spends its time, is the HIP kernel.
+#include <fcntl.h>
+#include <poll.h>
 #include <sys/resource.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -323,7 +325,11 @@ class MutPrefetcher {
   explicit MutPrefetcher(std::vector<std::string> files) : files_(std::move(files)), slots_(files_.size()) {
     const unsigned hc = std::thread::hardware_concurrency();
     int nthreads = (hc >= 6 && files_.size() > 1) ? (hc >= 12 ? 4 : 2) : 1;
-    if (const char* e = std::getenv("COLATE_THREADS")) nthreads = std::atoi(e) <= 1 ? 1 : std::min(nthreads, std::atoi(e));
+    // COLATE_THREADS=n: at most n threads of this process work on the inputs at a time, the caller's included --
+    // n <= 1: no thread is started at all (files are parsed by next() itself); n >= 2: up to min(4, n - 1) readers here,
+    // the rest of the n - 1 go to the age sampling (sample_threads(): readers and samplers overlap only while the
+    // fill waits for a file)
+    if (const char* e = std::getenv("COLATE_THREADS")) nthreads = std::atoi(e) <= 1 ? 0 : std::min(nthreads, std::atoi(e) - 1);
     for (int t = 0; t < nthreads; t++)
       workers_.emplace_back([this] {
         for (;;) {
@@ -358,6 +364,11 @@ class MutPrefetcher {
   }
   void next(std::vector<MutRow>& rows) {  // the next file's rows, in the order given
     const double t0 = StageTimes::now();
+    if (workers_.empty()) {  // COLATE_THREADS <= 1: on the calling thread
+      read_mut_file(files_[consumed_++], rows);
+      g_times.parse_mut += StageTimes::now() - t0;
+      return;
+    }
     std::unique_lock<std::mutex> lk(m_);
     const size_t i = consumed_;
     cv_.wait(lk, [&] { return slots_[i].ready; });
@@ -482,8 +493,13 @@ class SamplePool {
   void submit(SampleJob&& j) {
     const double t0 = StageTimes::now();
     std::unique_lock<std::mutex> lk(m_);
-    cv_room_.wait(lk, [this] { return q_.size() < 2 * workers_.size() + 2; });  // bounds the uniforms held in memory
+    // bounds the uniforms held in memory: a job is a whole genome block (800 bytes of uniforms per used SNP, 80 MB for a
+    // dense 100k-SNP block), so the queue is limited by its bytes -- kQueueBytes, or one job whatever its size -- as
+    // well as by its length
+    const size_t bytes = j.u.size() * sizeof(double);
+    cv_room_.wait(lk, [&] { return q_.empty() || (q_.size() < 2 * workers_.size() + 2 && queued_bytes_ + bytes <= kQueueBytes); });
     waited_ += StageTimes::now() - t0;
+    queued_bytes_ += bytes;
     q_.push_back(std::move(j));
     cv_work_.notify_one();
   }
@@ -509,6 +525,7 @@ class SamplePool {
         if (q_.empty()) return;
         j = std::move(q_.front());
         q_.pop_front();
+        queued_bytes_ -= j.u.size() * sizeof(double);
         cv_room_.notify_one();
       }
       if (redo_.load()) continue;
@@ -547,6 +564,8 @@ class SamplePool {
   std::mutex m_;
   std::condition_variable cv_work_, cv_room_;
   std::deque<SampleJob> q_;
+  static constexpr size_t kQueueBytes = size_t(256) << 20;
+  size_t queued_bytes_ = 0;
   bool done_ = false;
   std::atomic<bool> redo_{false};
 };
@@ -890,8 +909,10 @@ int fill_tables_impl(const std::vector<std::string>& chr_names,
   return num_blocks;
 }
 
-// coal.cpp:2071-2321 with the sampling on worker threads where the machine has them (COLATE_THREADS=n caps the threads of
-// this process, 1 = everything on the calling thread).  Returns the number of blocks.
+// coal.cpp:2071-2321 with the sampling on worker threads where the machine has them.  COLATE_THREADS=n: 1 = everything on the
+// calling thread, no thread is started (MutPrefetcher parses inline, the sequential path samples); n >= 2: n - 1 sampling
+// workers + the uniform-stream thread next to the caller, and up to min(4, n - 1) .mut readers that run ahead of the fill.
+// Returns the number of blocks.
 int fill_tables_from_tmp(const std::vector<std::string>& chr_names,
                          const std::vector<std::string>& mut_files, const std::string& target_file,
                          const std::string& ref_file, const std::vector<std::string>& target_masks,
@@ -1201,10 +1222,12 @@ int run_mut(const Options& opt) {
   const double t_em0 = StageTimes::now();
   if (g_rank.ranked) {
     // one process per GPU: this rank's contiguous replicate range on its own device, then ONE RCCL all-gather
-    if (const char* h = std::getenv("COLATE_TEST_HANG_RANK")) {  // test hook: a rank stuck as if inside a collective
+#ifdef COLATE_TEST_HOOKS  // (only in lib/testhooks/libcolate_amd.so, which the tests of the launcher load: never in the product library)
+    if (const char* h = std::getenv("COLATE_TEST_HANG_RANK")) {  // a rank stuck as if inside a collective
       if (std::atoi(h) == g_rank.rank)
         for (;;) ::pause();
     }
+#endif
     const int ndev = colate_device_count();
     if (ndev < 1) {
       std::cerr << "Error: " << colate_last_error() << std::endl;
@@ -1527,23 +1550,66 @@ int run_ranked(const Options& opt, int nranks) {
   }
   ::close(up[1]);
   for (int r = 1; r < nranks; r++) ::close(down_r[r]);
-  unsigned char id[COLATE_COMM_ID_BYTES];
-  if (read_all(up[0], id, sizeof(id)))  // else rank 0 failed first: closing the pipes below releases the others
-    for (int r = 1; r < nranks; r++) write_all(down_w[r], id, sizeof(id));
-  ::close(up[0]);
-  for (int r = 1; r < nranks; r++) ::close(down_w[r]);
-  // Reap the ranks as they end (our own pids only: this function is also reachable through the library ABI, whose host
-  // may have children of its own).  A rank that fails before or outside the collective leaves the others waiting in
-  // ncclCommInitRank / ncclAllGather for ever, so the first failure starts a grace period (COLATE_RANK_GRACE_SEC, default
-  // 15 s: ranks that are merely finishing get there) after which the remaining ranks are killed.
-  double grace_s = 15.0;
+  // One loop relays rank 0's communicator id to the other ranks AND reaps the ranks as they end (our own pids only: this
+  // function is also reachable through the library ABI, whose host may have children of its own).  Nothing here blocks:
+  //  * a rank that fails before or outside the collective leaves the others waiting in ncclCommInitRank / ncclAllGather
+  //    for ever, so the first failure -- or any exit while the id is still outstanding -- starts a grace period
+  //    (COLATE_RANK_GRACE_SEC, default 15 s: ranks that are merely finishing get there) after which the rest are killed;
+  //  * rank 0 ending without having published the id closes the other ranks' pipes (they report and exit);
+  //  * a rank 0 that neither publishes the id nor ends (stuck in HIP initialisation, ncclGetUniqueId or its table fill)
+  //    is given COLATE_RANK_ID_TIMEOUT_SEC (default 3600 s: the id follows the table fill, which may be long), then
+  //    every rank is killed and the launcher returns non-zero.
+  double grace_s = 15.0, id_timeout_s = 3600.0;
   if (const char* g = std::getenv("COLATE_RANK_GRACE_SEC")) grace_s = std::atof(g);
+  if (const char* g = std::getenv("COLATE_RANK_ID_TIMEOUT_SEC")) id_timeout_s = std::atof(g);
+  unsigned char id[COLATE_COMM_ID_BYTES];
+  size_t id_have = 0;
+  bool id_open = true;
+  auto close_id_pipes = [&]() {
+    if (!id_open) return;
+    ::close(up[0]);
+    for (int r = 1; r < nranks; r++) ::close(down_w[r]);
+    id_open = false;
+  };
+  ::fcntl(up[0], F_SETFL, ::fcntl(up[0], F_GETFL, 0) | O_NONBLOCK);
+  const auto t_start = std::chrono::steady_clock::now();
+  auto seconds_since = [](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+  };
   int worst = 0, remaining = nranks;
   std::vector<char> done(nranks, 0);
   bool failing = false, killed = false;
   auto t_fail = std::chrono::steady_clock::now();
+  auto kill_rest = [&]() {
+    for (int r = 0; r < nranks; r++)
+      if (!done[r]) ::kill(pids[r], SIGKILL);
+    killed = true;
+  };
   while (remaining > 0) {
     bool progressed = false;
+    if (id_open) {  // (waits up to 20 ms for bytes of the id: this is also the loop's pause)
+      pollfd pfd{up[0], POLLIN, 0};
+      if (::poll(&pfd, 1, 20) > 0) {
+        const ssize_t k = ::read(up[0], id + id_have, sizeof(id) - id_have);
+        if (k > 0) {
+          id_have += (size_t)k;
+          if (id_have == sizeof(id)) {
+            for (int r = 1; r < nranks; r++) write_all(down_w[r], id, sizeof(id));
+            close_id_pipes();
+          }
+          progressed = true;
+        } else if (k == 0) {  // rank 0 ended (or closed its end) without an id: end-of-file for the others, too
+          close_id_pipes();
+        }
+      }
+      if (id_open && !killed && seconds_since(t_start) > id_timeout_s) {
+        std::cerr << "Error: rank 0 has not published the communicator id after " << id_timeout_s
+                  << " s (COLATE_RANK_ID_TIMEOUT_SEC); ending all ranks." << std::endl;
+        close_id_pipes();
+        kill_rest();
+        worst = 1;
+      }
+    }
     for (int r = 0; r < nranks; r++) {
       if (done[r]) continue;
       int st = 0;
@@ -1556,20 +1622,21 @@ int run_ranked(const Options& opt, int nranks) {
         if (r > 0) std::cerr << " (see " << log_prefix << ".rank" << r << ".stderr)";
         std::cerr << std::endl;
         worst = 1;
-        if (!failing) failing = true, t_fail = std::chrono::steady_clock::now();
       }
+      // a failure -- or any exit while the id is outstanding (nobody can finish properly without it) -- starts the clock
+      if ((!ok || (id_open && nranks > 1)) && !failing) failing = true, t_fail = std::chrono::steady_clock::now();
     }
     if (remaining == 0) break;
-    if (failing && !killed &&
-        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fail).count() > grace_s) {
+    if (failing && !killed && seconds_since(t_fail) > grace_s) {
       std::cerr << "Error: a rank failed; ending the " << remaining << " rank(s) still waiting after " << grace_s << " s."
                 << std::endl;
-      for (int r = 0; r < nranks; r++)
-        if (!done[r]) ::kill(pids[r], SIGKILL);
-      killed = true;
+      close_id_pipes();
+      kill_rest();
+      worst = 1;
     }
-    if (!progressed) ::usleep(20000);
+    if (!progressed && !id_open) ::usleep(20000);
   }
+  close_id_pipes();
   return worst;
 }
 

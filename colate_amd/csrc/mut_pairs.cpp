@@ -771,7 +771,7 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
 
   // ---- the pairs, window by window through the shared uniform stream
   size_t window_mb = 64;
-  if (const char* e = std::getenv("COLATE_UNIFORM_WINDOW_MB")) window_mb = (size_t)std::max(8, std::atoi(e));
+  if (const char* e = std::getenv("COLATE_UNIFORM_WINDOW_MB")) window_mb = (size_t)std::max(4, std::atoi(e));
   const uint64_t W = std::max<uint64_t>(2, window_mb * (1u << 20) / (SharedUniforms::kChunk * sizeof(double)));  // chunks per window
   SharedUniforms stream((unsigned)seed, (size_t)(2 * W + 2));
   FastBin fastbin(A, C);

@@ -14,6 +14,7 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "colate_amd", "bin", "Colate")
+HOOKS_LIB_DIR = os.path.join(ROOT, "colate_amd", "lib", "testhooks")  # the library built with -DCOLATE_TEST_HOOKS (failure injection)
 
 
 @pytest.fixture(scope="module")
@@ -100,15 +101,29 @@ def test_two_ranks_one_fails_nobody_hangs(ca, tmp_path):
     gathered codes, both exit non-zero and the launcher returns promptly."""
     _two(ca)
     _, args = _stage(tmp_path)
-    r = _run(args + ["--ranks", "2"], tmp_path, COLATE_TEST_FAIL_RANK="1", COLATE_RANK_GRACE_SEC="20")
+    r = _run(args + ["--ranks", "2"], tmp_path, LD_LIBRARY_PATH=HOOKS_LIB_DIR, COLATE_TEST_FAIL_RANK="1", COLATE_RANK_GRACE_SEC="20")
     assert r.returncode != 0 and "rank 1" in r.stderr and not (tmp_path / "mine.coal").exists(), r.stderr[-800:]
     assert "ended by the launcher" not in r.stderr  # nobody had to be killed: the failing rank took part in the collective
+
+
+def test_rank0_hangs_before_the_id_launcher_still_returns(ca, tmp_path):
+    """Rank 0 hangs before it has published the communicator id while rank 1 waits for the id on its pipe: nobody exits,
+    so the launcher's bound on the wait for the id (COLATE_RANK_ID_TIMEOUT_SEC) must end both ranks."""
+    import time
+
+    _two(ca)
+    _, args = _stage(tmp_path)
+    t0 = time.time()
+    r = _run(args + ["--ranks", "2"], tmp_path, LD_LIBRARY_PATH=HOOKS_LIB_DIR, COLATE_TEST_HANG_RANK="0",
+             COLATE_RANK_ID_TIMEOUT_SEC="20", COLATE_RANK_GRACE_SEC="60")
+    assert r.returncode != 0 and "has not published the communicator id" in r.stderr, r.stderr[-800:]
+    assert r.stderr.count("ended by the launcher") == 2 and time.time() - t0 < 120 and not (tmp_path / "mine.coal").exists()
 
 
 def test_one_rank_injected_failure_is_reported(ca, tmp_path):
     """The same path with a communicator of one (any box): the injected failure comes back as this rank's error."""
     _, args = _stage(tmp_path)
-    r = _run(args + ["--ranks", "1"], tmp_path, COLATE_TEST_FAIL_RANK="0")
+    r = _run(args + ["--ranks", "1"], tmp_path, LD_LIBRARY_PATH=HOOKS_LIB_DIR, COLATE_TEST_FAIL_RANK="0")
     assert r.returncode != 0 and "injected failure on rank 0" in r.stderr, r.stderr[-800:]
     assert not (tmp_path / "mine.coal").exists()
 

@@ -15,6 +15,7 @@ import oracle_lib as ol
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "colate_amd", "bin", "Colate")
+HOOKS_LIB_DIR = os.path.join(ROOT, "colate_amd", "lib", "testhooks")  # the library built with -DCOLATE_TEST_HOOKS
 
 
 @pytest.fixture(scope="module")
@@ -396,15 +397,35 @@ def test_ranks_launcher_ends_waiting_ranks_after_a_failure(tmp_path):
         for _ in range(2):
             f.write(" ".join("1" for _ in grid) + "\n")
             f.write(" ".join("2" for _ in grid) + "\n")
-    env = dict(os.environ, COLATE_TEST_HANG_RANK="1", COLATE_RANK_GRACE_SEC="1", HIP_VISIBLE_DEVICES="",
-               ROCR_VISIBLE_DEVICES="")
+    cmd = [CLI, "--mode", "mut", "--mut", "dummy", "--bins", "3,7,0.2", "--num_bootstraps", "2", "--seed", "1",
+           "--ranks", "2", "-o", str(tmp_path / "out")]
+    # (the hooks exist in lib/testhooks/libcolate_amd.so only: the product library ignores these variables)
+    env = dict(os.environ, LD_LIBRARY_PATH=HOOKS_LIB_DIR, COLATE_TEST_HANG_RANK="1", COLATE_RANK_GRACE_SEC="1",
+               HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     t0 = time.time()
-    r = subprocess.run([CLI, "--mode", "mut", "--mut", "dummy", "--bins", "3,7,0.2", "--num_bootstraps", "2", "--seed", "1",
-                        "--ranks", "2", "-o", str(tmp_path / "out")], env=env, capture_output=True, text=True, timeout=60)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=60)
     took = time.time() - t0
     assert r.returncode != 0
     assert "rank 0 failed" in r.stderr and "ended by the launcher" in r.stderr, r.stderr
     assert took < 30
+    # Rank 0 itself hangs before it has published the communicator id, rank 1 waits for the id: nobody ever exits, so
+    # only the bound on the wait for the id can end the run (the relay used to block in front of the watchdog).
+    # (Without a device rank 1 fails on its own before it waits; the grace period is set long so that the bound on the id is
+    # what ends the run, as it must where rank 1 does wait: tests/test_gpu_multi_device.py has the two-GPU form.)
+    env.update(COLATE_TEST_HANG_RANK="0", COLATE_RANK_ID_TIMEOUT_SEC="2", COLATE_RANK_GRACE_SEC="60")
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=60)
+    took = time.time() - t0
+    assert r.returncode != 0 and "has not published the communicator id" in r.stderr, r.stderr
+    assert "rank 0 was ended by the launcher" in r.stderr and took < 30, (took, r.stderr)
+
+
+def test_product_library_has_no_test_hooks():
+    """The failure-injection / hang hooks are compiled into lib/testhooks/libcolate_amd.so only."""
+    prod = open(os.path.join(ROOT, "colate_amd", "lib", "libcolate_amd.so"), "rb").read()
+    hooks = open(os.path.join(HOOKS_LIB_DIR, "libcolate_amd.so"), "rb").read()
+    for name in (b"COLATE_TEST_HANG_RANK", b"COLATE_TEST_FAIL_RANK"):
+        assert name not in prod and name in hooks
 
 
 def test_ranks_refused_once_the_process_has_used_the_device(ca, tmp_path):
