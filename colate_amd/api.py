@@ -13,7 +13,7 @@ DEFAULT_MIN_ITER = 1000
 DEFAULT_REL_TOL = 1e-7
 DEFAULT_RATE_FLOOR = 5e-9
 DEFAULT_INIT_RATE = 1.0 / 20000.0
-MAX_EPOCHS = 256
+MAX_EPOCHS = 1024
 
 
 def _f64(a):
@@ -186,6 +186,21 @@ def bootstrap_em_batch_groups(age_grid_, ages, weights, tables, epochs, init_rat
                                                rate_floor, _p(rates), _p(iters), _p(ll), _p(flags),
                                                _p(csh) if want_counts else None, _p(cns) if want_counts else None))
     return (rates, iters, ll, flags, csh, cns) if want_counts else (rates, iters, ll, flags)
+
+
+def bootstrap_counts_groups_device(G, B, group_first, row_lo, row_hi, age_grid_, group_nb, group_block_off, group_weight_off, group_age,
+                                   weights, sh_block, ns_block, sh_emp_block, ns_emp_block, cnt_shared, cnt_notshared, status, stream=None):
+    """colate_bootstrap_counts_groups_device on torch tensors in HBM: the block bootstrap of rows [row_lo, row_hi) of G groups x B
+    replicates (group arrays from group `group_first` on: int32 nb, int64 block / weight offsets, float64 ages); asynchronous."""
+    A = age_grid_.numel()
+    for t in (age_grid_, group_nb, group_block_off, group_weight_off, group_age, weights, sh_block, ns_block, sh_emp_block, ns_emp_block,
+              cnt_shared, cnt_notshared, status):
+        assert t.is_cuda and t.is_contiguous()
+    check(lib.colate_bootstrap_counts_groups_device(int(G), int(B), int(group_first), int(row_lo), int(row_hi), A, age_grid_.data_ptr(),
+                                                    group_nb.data_ptr(), group_block_off.data_ptr(), group_weight_off.data_ptr(),
+                                                    group_age.data_ptr(), weights.data_ptr(), sh_block.data_ptr(), ns_block.data_ptr(),
+                                                    sh_emp_block.data_ptr(), ns_emp_block.data_ptr(), cnt_shared.data_ptr(),
+                                                    cnt_notshared.data_ptr(), status.data_ptr(), _stream_ptr(stream)))
 
 
 def write_coal(path, epochs, rates, is_ancient=False, ep_null=0):

@@ -175,6 +175,26 @@ __device__ __forceinline__ double half_ulp_pos(double z) {
   return ex > 53 ? __hiloint2double((ex - 53) << 20, 0) : 0.0;
 }
 
+// E[max(0, g - z)] for g ~ N(0, 1):  phi(z) - z Q(z)  (H(-z) of tools/study/residue_models.cpp; H(z) = z + H(-z)), and its
+// derivative -Q(z) through `q`.  The upper tail Q by Abramowitz & Stegun 26.2.17 (absolute error < 7.5e-8: plenty for a model
+// of rounding noise).
+// (Evaluated with the single-precision units -- v_exp_f32, v_rcp_f32, five v_fma_f32: 1e-7 relative, deterministic on the
+// device -- in a third of the instructions of the double-precision exp: the refresh evaluates it per (bin, epoch in transition).)
+__device__ __forceinline__ double tail_hneg(double z, double& q) {
+  const float a = __builtin_fminf(__builtin_fabsf((float)z), 30.0f);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.2316419f, a, 1.0f));
+  float poly = __builtin_fmaf(t, 1.330274429f, -1.821255978f);
+  poly = __builtin_fmaf(t, poly, 1.781477937f);
+  poly = __builtin_fmaf(t, poly, -0.356563782f);
+  poly = __builtin_fmaf(t, poly, 0.319381530f);
+  poly = poly * t;
+  const float phi = 0.3989422804f * __builtin_amdgcn_exp2f(-0.72134752f * (a * a));  // exp(-a^2 / 2)
+  const float qa = phi * poly;                                                         // Q(|z|)
+  const float base = __builtin_fmaxf(__builtin_fmaf(-a, qa, phi), 0.0f);
+  q = z < 0.0 ? (double)(1.0f - qa) : (double)qa;
+  return (z < 0.0 ? -z : 0.0) + (double)base;
+}
+
 #ifdef COLATE_EM_STAMPS
 // diagnostic build only (tools/em_phase_probe.hip): cycle stamps around the phases of an iteration
 __device__ __forceinline__ unsigned long long stamp() {
@@ -247,14 +267,16 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput, int wpe) {
   // The pad shifts everything behind it, the loops compiled per kind of wave included.
 #ifdef COLATE_EM_ILP_BUILD
   (void)tput;
-  // latency variant, max-ilp build, kernel ms for pads 0..7 (gpurun_out/r03z/pads13_* -> profiles/r03_placement.txt; final code of round 3):
-  // E=23 B=100 (the build without the register cap, two barriers) 0.892 0.906 0.898 0.886 0.878 0.890 0.907 0.890;
-  // E=23 B=400 (with the cap) 1.136 1.137 1.145 1.139 1.141 1.149 1.144 1.137; E=122 B=100 1.233 1.221 1.237 1.233 1.228 1.231 1.230 1.226
-  return nch == 1 ? (wpe == 2 ? 4 : 0) : 1;
+  // latency variant, max-ilp build, kernel ms for pads 0..7 (round 4, every loop anchored by itself: gpurun_out/r04_padsweep.txt ->
+  // profiles/r04_placement.txt; round 3's library on the same box: 0.883 / 1.217 / 1.140):
+  // E=23 B=100 (the build without the register cap, two barriers) 0.895 0.897 0.903 0.906 0.910 0.887 0.901 0.916;
+  // E=122 B=100 1.308 1.309 1.308 1.314 1.316 1.317 1.335 1.338 (with the tail model's per-iteration load still in the loop);
+  // E=23 B=400 (with the cap) 1.144 1.146 1.149 1.138 1.145 1.154 1.134 1.148
+  return nch == 1 ? (wpe == 2 ? 5 : 6) : 0;
 #else
   (void)nch;
   if (!tput) return 6;  // latency variant, default build (not picked by colate_em_variant any more; COLATE_EM_VARIANT=latency)
-  return 3;             // throughput variant: E=23 B=4096 6.297 6.309 6.316 6.213 6.351 6.364 6.327 6.360 (round 3, gpurun_out/r03z/pads13_*)
+  return 4;             // throughput variant: E=23 B=4096 6.347 6.291 6.272 6.320 6.193 6.286 6.279 6.313 (round 4, gpurun_out/r04_padsweep.txt; round 3's library: 6.206)
 #endif
 #endif
 }
@@ -294,8 +316,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   // Epoch e lives in lane e / NCH, slot e % NCH of the epoch-level waves: the NCH epochs of a lane are CONSECUTIVE, so a
   // scan over the epochs is one wave scan of the lanes' totals plus NCH - 1 local steps (round 2 kept chunks of 64
   // consecutive epochs per slot -- one wave scan per chunk -- and 65..128 epochs cost two of every scan)
-  constexpr int kSlotShift = (NCH == 1) ? 0 : (NCH == 2 ? 1 : 2);
-  static_assert(NCH == 1 || NCH == 2 || NCH == 4, "NCH");
+  constexpr int kSlotShift = (NCH == 1) ? 0 : (NCH == 2 ? 1 : (NCH == 4 ? 2 : (NCH == 8 ? 3 : 4)));
+  static_assert(NCH == 1 || NCH == 2 || NCH == 4 || NCH == 8 || NCH == 16, "NCH");
   auto ep_of = [&](int c) { return lane * NCH + c; };
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (a scalar: branches on role / group / wave are s_cbranch_scc)
   const int role = wave & 1;          // 0: shared (A), 1: not shared (B)
@@ -503,12 +525,16 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     for (int j = 0; j < 8; j++) c_all += v[j];
   }
   COLATE_PSTAMP(5)
-  // role A: dt_e * residue of the shared bins (0 in the last epoch, which has no dt_e * integ term).  Role B: the tail
+  // role A: dt_e * residue of the shared bins that reach the epoch (set with the bin ranges below).  Role B: the tail
   // model's correction R_e to the not-shared integ mass of the epoch (see `tail model` in P3), refreshed there.
-  double eta_e[NCH];
+  // (role B, more than 64 epochs -- where deep tails are the rule --: R_e is held as a linear function of the exact mass X_e = q_e T_e
+  // of the epoch (proportional to S_{e+1}), integ = eta_s X_e + eta_e with eta_s = 1 + dR_e / dX_e, between two refreshes that are up to 128 iterations apart; up to 64 epochs: as a constant, refreshed every 32nd
+  // iteration while some epoch is in transition -- with --bins 3,7,0.2 none ever is --, no instruction in the iteration)
+  constexpr bool kLinearHold = (NCH >= 2);
+  double eta_e[NCH], eta_s[NCH];
 #pragma unroll
-  for (int c = 0; c < NCH; c++) eta_e[c] = (role == 0) ? dt_e[c] * (kIntegResidue * c_all) : 0.0;
-  bool tail_trivial_prev = false;  // (uniform) the last full refresh of the tail model found no epoch in its transition zone
+  for (int c = 0; c < NCH; c++) eta_e[c] = 0.0, eta_s[c] = 1.0;
+  bool tail_trivial_prev = true;  // (uniform) the last full refresh of the tail model found no epoch in its transition zone
   if (tid < 2 * kWave && lane == 0) s_ll[8 + role] = c_all;  // both kinds' totals, for the epilogue (no register carries them)
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
@@ -516,7 +542,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     // The bins of epoch e are [lo, hi) -- the ages ascend, so the bins' epochs do --: two bisections of s_kb instead of a walk over
     // all bins per lane, which was 22 (42) us per launch at 23 (122) epochs.  An epoch without bins: lo == hi, no tail slots.
     int lo = A, hi = 0, n_before = 0;
-    double c_later = 0.0;
+    double c_later = 0.0, c_ge = 0.0;
     if (ep_on[c]) {
       lo = hi = 0;
       for (int len = A; len > 0;) {  // first b with s_kb[b] >= e
@@ -542,17 +568,28 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     }
     {  // counts of the later bins, b >= hi, summed in ascending order as before (a bin outside the data has a count of 0, and
        // x + 0.0 == x): one walk over the bins with data for the whole wave, every lane adding from its own hi on
-      int b0 = __builtin_amdgcn_readfirstlane(hi);  // (lane 0 holds the slot's earliest epoch: the smallest hi)
+      // (c_ge: the counts of the epoch's own bins and the later ones, b >= lo -- the bins whose own integ chain reaches this
+      // epoch, coal_EM.cpp:266-278 --; the walk starts at the slot's smallest lo, and the extra zeros leave c_later's bits alone)
+      int b0 = __builtin_amdgcn_readfirstlane(lo);  // (lane 0 holds the slot's earliest epoch: the smallest lo and hi)
       if (b0 < nzlo) b0 = nzlo;
       for (int b = b0; b < nzhi; b += 8) {  // (eight loads in flight; the row is zero from nzhi up to AP)
         double v[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) v[j] = s_cnt[role * APZ + b + j];
 #pragma unroll
-        for (int j = 0; j < 8; j++) c_later += (ep_on[c] && b + j >= hi) ? v[j] : 0.0;
+        for (int j = 0; j < 8; j++) {
+          c_later += (ep_on[c] && b + j >= hi) ? v[j] : 0.0;
+          c_ge += (ep_on[c] && b + j >= lo) ? v[j] : 0.0;
+        }
       }
     }
     C0[c] = c_later;
+    // role A: dt_e * mean residue of the shared bins WHOSE CHAIN REACHES EPOCH e (0 in the last epoch, which has no dt_e * integ
+    // term).  A shared bin's integ recurrence stops at the bin's own epoch (coal_EM.cpp:266-278: e = 0 .. min(E - 2, k)); behind
+    // it the bin adds nothing to any denominator -- round 3 charged every epoch with the residue of ALL shared counts, which in
+    // the flat epochs behind all data pulled the rate down ten times faster than any real build of the reference does
+    // (profiles/parity/ref_self_reproducibility_e122.json: epoch 109 of --bins 2,7.95,0.05).
+    if (role == 0) eta_e[c] = dt_e[c] * (kIntegResidue * c_ge);
     nlt[c] = n_before;
     const int clo = (lo > nzlo ? lo : nzlo) - nzlo, chi = (hi < nzhi ? hi : nzhi) - nzlo;  // compacted, clipped
     seg_hi[c] = chi;
@@ -659,17 +696,22 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   // instruction-fetch lines (measured: the same loop shifted in 4-byte steps has a period of 8 dwords, best to worst
   // 1.362 .. 1.430 ms at B = 100; profiles/r02_placement.txt) -- and every edit of the prologue used to shift it.  The loop
   // is therefore pinned to a 64-byte boundary plus em_loop_pad() dwords, tuned per instantiation on the GPU.
-  {
-    constexpr int kPad = em_loop_pad(MODE, NCH, EROWS, TPUT, WPE);
+  // Round 4: EVERY loop compiled per kind of wave is pinned by itself (COLATE_LOOP_ANCHOR in front of each loop below) -- with
+  // one anchor in front of them all, an edit of any loop, or of the refresh iteration that sits between them, moved every
+  // loop behind it: the same iteration code measured 1.151, 1.161, 1.214 and 1.240 us at E = 122 in four builds of this round
+  // that differed in the refresh block only (profiles/r04_placement.txt).  An anchor is executed once per entry of a loop.
+  constexpr int kPad = em_loop_pad(MODE, NCH, EROWS, TPUT, WPE);
 #define COLATE_PAD_CASE(n) \
   if constexpr (kPad == n) asm volatile(".p2align 6\n\t.rept " #n "\n\ts_nop 0\n\t.endr");
-    COLATE_PAD_CASE(0) COLATE_PAD_CASE(1) COLATE_PAD_CASE(2) COLATE_PAD_CASE(3)
-    COLATE_PAD_CASE(4) COLATE_PAD_CASE(5) COLATE_PAD_CASE(6) COLATE_PAD_CASE(7)
-#undef COLATE_PAD_CASE
+#define COLATE_LOOP_ANCHOR()                                            \
+  {                                                                     \
+    COLATE_PAD_CASE(0) COLATE_PAD_CASE(1) COLATE_PAD_CASE(2) COLATE_PAD_CASE(3) \
+    COLATE_PAD_CASE(4) COLATE_PAD_CASE(5) COLATE_PAD_CASE(6) COLATE_PAD_CASE(7) \
   }
-  // The tail model (P3, role B leader) is refreshed in iterations 0, 1, 2, 4, 8, ... (powers of two) and held in between:
-  // its inputs move fast while the rates leave their starting values and ever more slowly afterwards (tools/study/
-  // residue_models.cpp: the final rates stay within the reference's own libm-noise spread of the per-iteration evaluation).
+  // The tail model (P3, role B leader) is refreshed in iterations 0, 1, 2, 4, ..., 128 and then every 128th, and held in between
+  // as a linear function of S_{e+1} (tools/study/residue_models.cpp, model 8: with a period of up to 256 the final rates of the
+  // flat epochs stay inside the range of the reference's real builds; held as a constant, model 6, only up to 32; round 3's
+  // powers of two held a constant for up to 512 iterations).
   // free mode: the last rate is positive (after the latest M-step; the same in every wave) -- what the loops compiled per kind of
   // wave assume; always true otherwise (those loops test it themselves where it matters)
   bool last_pos = true;
@@ -693,8 +735,20 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   const unsigned long long last_bit1 = 1ull << ((E - 1) & 63);  // (one epoch per lane: the last epoch's lane)
   if (kFree) last_pos = (ballot64(lam_e[0] > 0.0) & last_bit1) != 0ull;
   if (TPUT) last_pos = last_rate_positive();
-  auto tail_due = [&](int it) { return (it & (it - 1)) == 0; };
-  auto tail_next_due = [&](int it) { return it <= 1 ? it : (1 << (32 - __builtin_clz((unsigned)(it - 1)))); };  // first due iteration >= it
+  // (the tail model's refresh schedule -- see `tail model` in P3.  More than 64 epochs: the powers of two up to 128 and then
+  // every 128th iteration.  Up to 64: the powers of two, and every 32nd iteration while the last refresh found an epoch in
+  // transition; the flag only changes inside a refresh, so due / next-due stay consistent along a run.)
+  auto tail_due = [&](int it) {
+    if (NCH >= 2) return it < 128 ? (it & (it - 1)) == 0 : (it & 127) == 0;
+    return (it & (it - 1)) == 0 || (!tail_trivial_prev && (it & 31) == 0);
+  };
+  auto tail_next_due = [&](int it) {  // first due iteration >= it
+    if (it <= 1) return it;
+    const int p2 = 1 << (32 - __builtin_clz((unsigned)(it - 1)));
+    if (NCH >= 2) return it <= 128 ? p2 : ((it + 127) & ~127);
+    const int m32 = (it + 31) & ~31;
+    return (!tail_trivial_prev && m32 < p2) ? m32 : p2;
+  };
   auto iteration = [&](auto role_c, auto leader_c, auto ll_c, auto track_c, auto refresh_c, auto p1_c) __attribute__((always_inline)) -> bool {
     COLATE_STAMP(7)
     // (compile-time role / leadership / "no log-likelihood needed" in the steady-state loops below; -1 = run-time value)
@@ -1193,15 +1247,25 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
         // (i) a fold step whose increment is below half an ulp of the running value Z_b (|Z_b| ~ cs(age)) leaves it unchanged:
         // those terms are missing from the normaliser but are still subtracted, so integ_ref = x_be - D_b with D_b the mass
         // of the absorbed terms (a NEGATIVE bias of ~ulp(cs(age))/2, which accumulates over the iterations in the flat epochs
-        // behind all data); (ii) the clamp `integ > 0 ? integ - n : 0` keeps what is left at >= 0; (iii) the roundings of
-        // the chain (2^-54 per step while integ is in [0.5, 1)) and of the fold (ulp(Z_b)/2 per step) add zero-mean noise of
-        // standard deviation s_b, whose positive part, 0.4 s_b, is what remains once x_be has fallen below D_b:
-        //     integ_ref(b, e) ~ max(x_be - D_b, rho_b),  rho_b = 0.4 s_b,  x_be = S_{e+1} / S(age_b).
-        // Bins are cut (x_be - D_b < rho_b) youngest first, so with tau_b = (D_b + rho_b) S(age_b), made monotone, the cut set
-        // of epoch e is a prefix of the bins and the correction to the exact mass q_e T_e is
-        //     R_e = sum_{cut} c_b (rho_b + D_b) - S_{e+1} sum_{cut} c_b / S(age_b) - [e behind all data] sum_b c_b D_b
-        // from two prefix sums over the bins and one search per epoch.  It moves slowly, so it is refreshed in iterations
-        // 0, 1, 2, 4, 8, ... only (tail_due above) and held in between.
+        // behind all data); (ii) the roundings of the chain (2^-54 per step while integ is in [0.5, 1)) and of the fold
+        // (ulp(Z_b)/2 per step) add an error eps_b of standard deviation s_b that is made while integ is large and stays
+        // FROZEN from there on: integ(b, e) = x_be - D_b + eps_b for all later epochs; (iii) the clamp `integ > 0 ? integ - n
+        // : 0` cuts it at zero for good.  eps_b itself depends on the last bits of every exp() and log(); its expectation
+        // does not:
+        //     integ_ref(b, e) ~ E max(0, x_be - D_b + eps_b) = s_b H((x_be - D_b) / s_b),   H(z) = phi(z) + z Phi(z),
+        // x_be = S_{e+1} / S(age_b).  The correction to the exact mass q_e T_e = sum_b c_b x_be of the epoch is therefore
+        //     R_e = sum_{b: k_b < e} c_b s_b (H(z_be) - x_be / s_b) = sum w_b (Hneg(z_be) - d_b),
+        // w_b = c_b s_b, d_b = D_b / s_b, z_be = S_{e+1} a_b - d_b, a_b = 1 / (S(age_b) s_b), Hneg(z) = H(-z) = H(z) - z.
+        // Three regimes per epoch: every bin far above its threshold (z > 8: R_e = -sum c_b D_b), every bin far below (x <<
+        // s: R_e = sum w_b H(-d_b) - S_{e+1} sum c_b / S(age_b)), and the two to eight epochs in between, where the sum
+        // over the bins is evaluated term by term.  Round 3 used max(x_be - D_b, 0.4 s_b) -- the same at both ends, but up to
+        // 0.4 s_b too much wherever D_b exceeds s_b, i.e. for every bin with absorbed terms -- and held R_e for up to 512
+        // iterations; against five real builds of the reference (tools/ref_self_reproducibility.py) that put epoch 109 of
+        // --bins 2,7.95,0.05 at 6e-6 where the builds print 3e-5 .. 5e-5.  R_e depends on the tail epochs' own rates through
+        // S_{e+1}, which drift for hundreds of iterations: it is refreshed in iterations 0, 1, 2, 4, ..., 128 and then every
+        // 128th (tail_due above) together with its derivative -sum w_b a_b Q(z_be), and held in between as A + B S_{e+1}
+        // (tools/study/residue_models.cpp, model 8: every refresh period up to 256 ends inside the builds' range; a
+        // held constant, model 6, only up to 32).
         if constexpr (kRefresh != 0) {
           const bool due = kRefresh > 0 || tail_due(iter);
           if (__builtin_expect(due, kRefresh > 0)) {
@@ -1210,7 +1274,8 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
             const int e_o1 = (k_old + 1 < E - 1) ? (k_old + 1 > 0 ? k_old + 1 : 0) : E - 1;
             const double S_old1 = s_ep[G_S * EPAD + e_o1];  // no bin's S(age) is below this
             double S1[NCH], We[NCH];
-            unsigned long long between = 0, small_w[NCH];
+            bool alive_l[NCH], dead_l[NCH];
+            unsigned long long between[NCH], small_w[NCH], any_between = 0;
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
               const int e = ep_of(c);
@@ -1219,24 +1284,28 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
               const double pe = (kSplit && !own(c)) ? s_ep[G_P * EPAD + e] : p_e[c];
               We[c] = ep_on[c] ? s_ep[G_S * EPAD + e] * pe : 0.0;  // the fold's term of epoch e per unit S(age)
               S1[c] = has ? s_ep[G_S * EPAD + e + 1] : 1.0;
-              // mass beyond t_{e+1} per unit count of the earlier bins: exact with one epoch per lane; with more, where a wave may
-              // own one slot only, its lower bound S_{e+1} (every 1 / S(age) >= 1), so that all owners decide alike
-              const double Ie = (NCH == 1) ? q_e[c] * T[c] : S1[c] * (c_all - C0[c]);
-              // no bin can be cut while S_{e+1} >= 1e-14 (tau_b <= 3 2^-53 max(cs e^-cs) + chain noise < 3e-16), and sum c D
-              // (<= 1e-16 per unit count) is below 1e-12 of the mass while that is >= 1e-4 per unit count -- in the epochs
-              // behind all data, where the bias accumulates over the iterations (the likelihood is flat in their rates);
-              // in an epoch with data it only shifts the fixed point by that ratio, so 1e-8 per unit count is plenty there;
-              // every bin is cut once S_{e+1} / S(oldest age) < 2e-17 (rho_b >= 0.4 2^-54)
+              // Behind all data (the flat epochs, where a bias accumulates over the iterations): every bin is far above its
+              // threshold while S_{e+1} >= 1e-11 (x_be >= S_{e+1}; D_b + 8 s_b < 1e-12: D_b is at most ~20 half-ulps of
+              // cs <= 32, s_b a few of them).  In an epoch with data the correction only shifts the fixed point by its ratio to
+              // the mass: nothing to do while that mass is >= 1e-8 per unit count of the earlier bins (and no bin is below
+              // S_{e+1} = 1e-14).  Every bin is far below its threshold (x_be < 1e-3 s_b) once S_{e+1} / S(oldest age) < 4e-20
+              // (s_b >= 0.7 2^-54) -- taken only behind all data, where every bin is in an earlier epoch.
               // (an epoch without bins in earlier epochs has no such mass at all)
-              const double need = (e > k_old) ? 1e-4 : 1e-8;
-              const bool alive = !has || nlt[c] == 0 || (S1[c] >= 1e-14 && Ie >= need * (c_all - C0[c]));
-              const bool dead = has && S1[c] < 2e-17 * S_old1;
-              between |= ballot64(!(alive || dead));
+              // (mass beyond t_{e+1} per unit count of the earlier bins: exact with one epoch per lane; with more, where a wave
+              // may own one slot only, its lower bound S_{e+1} (every 1 / S(age) >= 1), so that all owners decide alike)
+              const double Ie = (NCH == 1) ? q_e[c] * T[c] : S1[c] * (c_all - C0[c]);
+              alive_l[c] = !has || nlt[c] == 0 ||
+                           ((e > k_old) ? S1[c] >= 1e-11 : (S1[c] >= 1e-14 && Ie >= 1e-8 * (c_all - C0[c])));
+              dead_l[c] = has && e > k_old && S1[c] < 4e-20 * S_old1;
+              between[c] = ballot64(ep_on[c] && !(alive_l[c] || dead_l[c]));
+              any_between |= between[c];
               // a bin absorbs epoch e's term iff W_e / S(age) < ulp(cs(age))/2 <= cs 2^-53, and cs e^-cs <= 1/e
               // (a term of exactly 0 -- an epoch without a valid rate, or underflow -- adds nothing either way)
               small_w[c] = ballot64(ep_on[c] && We[c] < 0x1p-53 * 0.37 && We[c] > 0.0);
             }
-            const bool trivial = (between == 0);
+            // (nothing in transition now nor at the last refresh: every epoch keeps one of the two closed forms, whose inputs
+            // -- D_b, s_b of the bins -- move slowly: they are brought up to date every 256 iterations)
+            const bool trivial = (any_between == 0);
             if (!(trivial && tail_trivial_prev && (iter & 255) != 0)) {
               tail_trivial_prev = trivial;
               int e_sm = E;  // first epoch whose term some bin may absorb
@@ -1250,11 +1319,10 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
               // again only behind barriers 3 and 1); with more, the owners of a role run this refresh side by side (same inputs,
               // same values, not synchronised) while the other may still be loading its tails: each has arrays of its own
               double* const scr = s_tscr + (kSplit ? kOwn * 3 * APZ : 0);
-              double* const s_tau = (NCH == 1) ? out_mine + O_W * APZ : scr;
-              double* const s_PQ = (NCH == 1) ? out_mine + O_N * APZ : scr + APZ;
-              double* const s_PM = (NCH == 1) ? out_mine + O_D * APZ : scr + 2 * APZ;
-              const int nbt = NB * kWave;
-              double carryQ = 0.0, carryM = 0.0, PDtot = 0.0;
+              double* const s_w = (NCH == 1) ? out_mine + O_W * APZ : scr;
+              double* const s_a = (NCH == 1) ? out_mine + O_N * APZ : scr + APZ;
+              double* const s_d = (NCH == 1) ? out_mine + O_D * APZ : scr + 2 * APZ;
+              double PDtot = 0.0, PHtot = 0.0, PMtot = 0.0;
               for (int g = 0; g < NB; g++) {  // the not-shared bins, youngest group first
                 const int gpos = g * kWave + lane, gbin = nzlo + gpos;
                 const bool inr = gbin < nzhi;
@@ -1284,44 +1352,59 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
                 double nh = (double)(E - kq);  // chain steps taken while integ is still in [0.5, 1): ~ln 2 / (lambda dt)
                 if (xk > 0.0) nh = __builtin_fmin(0.69 * em::em_rcp(xk), nh);
                 nh += 1.5;
-                const double rho = 0.4 * __builtin_amdgcn_sqrt((0x1p-108 / 3.0) * nh + th * th * ((double)nfold * (1.0 / 3.0)));
-                const double tau = liveb ? (Db + rho) * em::em_rcp(mb) : 0.0;
-                const double cq = liveb ? cntb * (rho + Db) : 0.0, cm = liveb ? cntb * mb : 0.0, cd = liveb ? cntb * Db : 0.0;
-                const double iq = wave_prefix_sum(cq), im = wave_prefix_sum(cm);
-                s_tau[gpos] = tau;
-                s_PQ[gpos] = carryQ + (iq - cq);  // exclusive prefix sums over the bins in age order
-                s_PM[gpos] = carryM + (im - cm);
-                carryQ = carryQ + readlane_d(iq, 63);
-                carryM = carryM + readlane_d(im, 63);
+                const double sb = __builtin_amdgcn_sqrt((0x1p-108 / 3.0) * nh + th * th * ((double)nfold * (1.0 / 3.0)));
+                const double rsb = em::em_rcp(sb);
+                const double wv = liveb ? cntb * sb : 0.0, av = liveb ? mb * rsb : 0.0, dv = liveb ? Db * rsb : 0.0;
+                s_w[gpos] = wv;
+                s_a[gpos] = av;
+                s_d[gpos] = dv;
+                double qd;
+                const double ch = wv * tail_hneg(dv, qd);  // c_b s_b H(-d_b): what is left of a bin deep in the tail
+                const double cm = liveb ? cntb * mb : 0.0, cd = liveb ? cntb * Db : 0.0;
+                PHtot = PHtot + readlane_d(wave_prefix_sum(ch), 63);
+                PMtot = PMtot + readlane_d(wave_prefix_sum(cm), 63);
                 PDtot = PDtot + readlane_d(wave_prefix_sum(cd), 63);
-              }
-              // (the totals stay in registers: entry AP of the tile is the tail loads' zero entry and nbt may equal AP)
-              wave_lds_fence();
-              double tau_max = 0.0;
-              for (int g = NB - 1; g >= 0; g--) {  // tau made non-increasing in age order: the cut set is a prefix
-                double tv = wave_suffix_max(s_tau[g * kWave + lane], lane);
-                tv = __builtin_fmax(tv, tau_max);
-                s_tau[g * kWave + lane] = tv;
-                tau_max = readlane_d(tv, 0);
               }
               wave_lds_fence();
 #pragma unroll
               for (int c = 0; c < NCH; c++) {
                 const int e = ep_of(c);
-                int bs = 0;  // bins with tau > S_{e+1}
-                if (ballot64(S1[c] < tau_max) != 0) {
-                  for (int step = 256; step >= 1; step >>= 1) {
-                    const int idx = bs + step;
-                    const bool ok = idx <= nbt;
-                    const double tv = s_tau[ok ? idx - 1 : 0];
-                    if (ok && tv > S1[c]) bs = idx;
+                // R_e as a linear function of S_{e+1} around its current value, R_e = A + B S_{e+1}: what is held until the next
+                // refresh (the tail epochs' own rates drift for hundreds of iterations, and S_{e+1} with them).  The two closed
+                // forms are linear as they stand (an epoch in transition is overwritten below)
+                double Ra = alive_l[c] ? ((e > k_old) ? -PDtot : 0.0) : PHtot;
+                double Rb = alive_l[c] ? 0.0 : -PMtot;
+                // (the epochs of this slot in transition, one after the other -- uniform --; with the epochs split over two waves
+                // each owner needs the correction of its own slot only)
+                for (unsigned long long m = own(c) ? between[c] : 0ull; m != 0; m &= m - 1) {
+                  const int l = __builtin_ctzll(m);
+                  const double S1e = readlane_d(S1[c], l);
+                  const int nlte = __builtin_amdgcn_readlane(nlt[c], l);  // only bins of earlier epochs have a term in this epoch's integ
+                  double acc = 0.0, acc1 = 0.0;
+                  for (int g = 0; g < NB; g++) {
+                    const int gpos = g * kWave + lane;
+                    const double dv = s_d[gpos], av = s_a[gpos], wv = s_w[gpos];
+                    double qz;
+                    const double term = wv * (tail_hneg(S1e * av - dv, qz) - dv);
+                    acc += (gpos < nlte) ? term : 0.0;
+                    acc1 += (gpos < nlte) ? (wv * av) * qz : 0.0;  // -d term / d S_{e+1}
                   }
+                  const double r0 = readlane_d(wave_prefix_sum(acc), 63), r1 = -readlane_d(wave_prefix_sum(acc1), 63);
+                  Ra = (lane == l) ? r0 - r1 * S1e : Ra;
+                  Rb = (lane == l) ? r1 : Rb;
                 }
-                if (bs > nlt[c]) bs = nlt[c];  // (only bins of earlier epochs have a term in this epoch's integ)
-                const bool all_b = bs >= nbt;
-                const double pq = all_b ? carryQ : s_PQ[all_b ? 0 : bs], pm = all_b ? carryM : s_PM[all_b ? 0 : bs];
-                const double R = (pq - S1[c] * pm) - ((e > k_old) ? PDtot : 0.0);
-                eta_e[c] = (ep_on[c] && e < E - 1) ? R : 0.0;
+                const bool on = ep_on[c] && e < E - 1;
+                if (kLinearHold) {
+                  // in terms of what the iteration has in registers anyway: the exact mass X_e = q_e T_e = S_{e+1} sum_b c_b / S(age_b),
+                  // whose second factor is a matter of the data epochs' rates (as a_b is): R_e = Ra + Rb (S1_0 / X_0) X_e, and
+                  // integ = X_e + R_e = (1 + Rb S1_0 / X_0) X_e + Ra -- the factor replaces the 1.0 the mass is multiplied with
+                  const double X0 = q_e[c] * T[c];
+                  const bool lin = on && own(c) && X0 > 0.0;
+                  eta_e[c] = on ? (lin ? Ra : Ra + Rb * S1[c]) : 0.0;
+                  eta_s[c] = lin ? 1.0 + Rb * (S1[c] * em::em_rcp(X0)) : 1.0;
+                } else {
+                  eta_e[c] = on ? Ra + Rb * S1[c] : 0.0;  // the value at the current S_{e+1}
+                }
               }
             }
           }
@@ -1332,14 +1415,16 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
           if (!own(c)) continue;
           const int e = ep_of(c);
           Npart[c] = p_e[c] * T[c] + oN[c];
-          double Gn = 1.0;  // mass still to coalesce after t_{e+1}, relative to survival there
+          // mass still to coalesce after t_{e+1}, relative to survival there (more than 64 epochs: times the slope of the tail
+          // model's held correction, 1 + dR_e / dX_e, see the refresh)
+          double Gn = kLinearHold ? eta_s[c] : 1.0;
           if (__builtin_expect(!absorbing, 0)) {
             COLATE_COLD();
-            if (e < E - 1) Gn = 1.0 - em::em_exp_t(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + e + 1], s_exptab);
+            if (e < E - 1) Gn = (1.0 - em::em_exp_t(-s_ep[G_CS * EPAD + E - 1] + s_ep[G_CS * EPAD + e + 1], s_exptab)) + (Gn - 1.0);
           }
           // later not-shared bins contribute dt_e each, earlier ones their tail mass (last epoch: dt_e = 0 and q_e = 0
           // leave (beta - t p) T, coal_EM.cpp:136-141, without a branch)
-          const double integ_ns = __builtin_fmax(Gn * (q_e[c] * T[c]) + eta_e[c], 0.0);  // (eta_e: the tail model's R_e)
+          const double integ_ns = __builtin_fmax(Gn * (q_e[c] * T[c]) + eta_e[c], 0.0);  // (eta_e: the tail model's R_e, its intercept)
           double dns = dt_e[c] * Cn[c] + ((beta_e[c] - t_e[c] * p_e[c]) * T[c] + dt_e[c] * integ_ns);
           dns = __builtin_fmax(dns, 0.0);
           Dpart[c] = dns + oD[c];
@@ -1477,7 +1562,9 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   // The waves of a workgroup run different loops but the same sequence of barriers.  The general loop below is what is
   // left for MODE 1 and for the rare wave whose epochs need more than two tail slots.
   bool stopped = false;
-  if (MODE == 0 && p.ll_trace == nullptr) {  // (the per-iteration log-likelihood trace runs everything in the general loop)
+  // (8 and 16 epochs per lane -- 257 .. 1024 epochs, em_kernels_big.hip -- run everything in the general loop: the reference has no
+  // limit on the number of epochs, coal.cpp:3551-3632, and neither has the drop-in; speed is secondary there)
+  if constexpr (NCH <= 4) if (MODE == 0 && p.ll_trace == nullptr) {  // (the per-iteration log-likelihood trace runs everything in the general loop)
     int n_steady = p.min_iter < max_iter - 1 ? p.min_iter : max_iter - 1;
     if (n_steady < 0) n_steady = 0;
     using C0 = std::integral_constant<int, 0>;
@@ -1486,6 +1573,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
 #define COLATE_STEADY(R, L, T, P)                             \
   {                                                           \
     lim = n_steady;                                           \
+    COLATE_LOOP_ANCHOR()                                      \
     do {                                                      \
       iteration(R{}, L{}, C0{}, T{}, C0{}, P{});              \
     } while (__builtin_expect(++iter < lim, 1));              \
@@ -1504,6 +1592,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     }                                                                                  \
     lim = tail_next_due(iter);                                                         \
     if (lim > n_steady) lim = n_steady;                                                \
+    COLATE_LOOP_ANCHOR()                                                               \
     while (__builtin_expect(iter < lim, 1)) {                                          \
       iteration(R{}, L{}, C0{}, T{}, C0{}, P{});                                       \
       ++iter;                                                                          \
@@ -1522,6 +1611,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
 #define COLATE_STEADY_LL(R, L, T, P)                          \
   if (last_pos) {                                             \
     lim = max_iter;                                           \
+    COLATE_LOOP_ANCHOR()                                      \
     for (; iter < lim; iter++) {                              \
       if (iteration(R{}, L{}, C1{}, T{}, C0{}, P{})) {        \
         stopped = true;                                       \
@@ -1544,6 +1634,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     }                                                                                  \
     lim = tail_next_due(iter);                                                         \
     if (lim > max_iter) lim = max_iter;                                                \
+    COLATE_LOOP_ANCHOR()                                                               \
     for (; iter < lim; iter++) {                                                       \
       if (iteration(R{}, L{}, C1{}, T{}, C0{}, P{})) {                                 \
         stopped = true;                                                                \
@@ -1656,6 +1747,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     // needed" only: no cost for the steady loops, 2.20 -> 2.08 us per iteration at E = 122
     if constexpr (NCH > COLATE_LL_MAX_NCH) if (!(any_more_rows || third_row) && last_pos) {
       lim = max_iter;
+      COLATE_LOOP_ANCHOR()
       for (; iter < lim; iter++) {
         if (iteration(CR{}, CR{}, C1{}, CR{}, CR{}, CR{})) {
           stopped = true;
@@ -1665,6 +1757,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
       if (kAssumeAbsorbing && lim == 0) last_pos = false;
     }
   }
+  COLATE_LOOP_ANCHOR()
   for (; !stopped && iter < max_iter; iter++) {
     using CRt = std::integral_constant<int, -1>;
     if (iteration(CRt{}, CRt{}, CRt{}, CRt{}, CRt{}, CRt{})) break;
@@ -1787,7 +1880,7 @@ hipError_t launch_one(const ColateEmArgs& args, hipStream_t stream, size_t lds, 
 
 inline int em_groups(int A) { return (A + 63) / 64; }           // bin groups of 64 per role
 inline int em_threads(int A) { return 2 * 64 * em_groups(A); }  // two roles (latency variant)
-inline int em_chunks(int E) { return E <= 64 ? 1 : (E <= 128 ? 2 : 4); }
+inline int em_chunks(int E) { return E <= 64 ? 1 : (E <= 128 ? 2 : (E <= 256 ? 4 : (E <= 512 ? 8 : 16))); }
 inline int em_rows(int E) { return E <= 16 ? 1 : (E <= 32 ? 2 : 4); }  // BASELINE's `--bins 3,7,0.2` gives E = 23
 
 inline size_t em_lds_bytes(int E, int A, bool tput) {

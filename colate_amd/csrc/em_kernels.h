@@ -5,7 +5,7 @@
 #include <cstddef>
 
 #define COLATE_EM_THREADS 256
-#define COLATE_EM_MAX_E 256  // one epoch per thread
+#define COLATE_EM_MAX_E 1024  // up to 16 epochs per lane of a 64-lane wave (em_kernels_big.hip beyond 256)
 #define COLATE_EM_MAX_A 256  // one age bin per thread
 
 // per-replicate diagnostic flags (the reference aborts on the corresponding asserts)

@@ -5,6 +5,7 @@
 //   B <= 2 x #CUs, E <= 128                 <0, NCH, EROWS, false> latency    em_kernels_ilp.hip (max-ilp scheduling; fits 3 waves/SIMD)
 //   only by COLATE_EM_VARIANT=latency       <0, NCH, EROWS, false> latency    this unit (default scheduler; A/B runs)
 //   B > 2 x #CUs, or E > 128                <0, NCH, EROWS, true> throughput  this unit
+//   256 < E <= 1024                         <*, 8 | 16, 4, *> two-wave layout   em_kernels_big.hip (general loop only)
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -12,6 +13,7 @@
 #include "em_kernel_impl.hpp"
 
 hipError_t colate_em_launch_latency_ilp(const ColateEmArgs& args, hipStream_t stream, bool alone);  // em_kernels_ilp.hip
+hipError_t colate_em_launch_big(const ColateEmArgs& args, hipStream_t stream);                          // em_kernels_big.hip: 257 .. 1024 epochs
 
 size_t colate_em_lds_bytes(int E, int A) { return em_lds_bytes(E, A, false); }  // (the larger of the two variants' needs)
 
@@ -61,6 +63,7 @@ int colate_em_variant(int B, int E) {
 
 hipError_t colate_em_launch(const ColateEmArgs& args, hipStream_t stream) {
   const int nch = em_chunks(args.E);
+  if (nch > 4) return colate_em_launch_big(args, stream);
   if (args.mode == 1) {
     const int threads = em_threads(args.A);
     const size_t lds = em_lds_bytes(args.E, args.A, false);

@@ -32,7 +32,7 @@ extern "C" {
 #define COLATE_EINVAL (-1)    /* bad argument (sizes, NULL, unsorted grids, ...) */
 #define COLATE_ENODEVICE (-2) /* no usable HIP device                            */
 #define COLATE_EHIP (-3)      /* a HIP runtime call failed                       */
-#define COLATE_ELIMIT (-4)    /* E or A above the compiled limits (256 each)     */
+#define COLATE_ELIMIT (-4)    /* E above 1024 or A above 256 (compiled limits)   */
 #define COLATE_EIO (-5)       /* file could not be read / written                */
 
 /* per-replicate flags in out_flags[]: conditions on which the reference aborts
@@ -57,8 +57,9 @@ extern "C" {
 #define COLATE_STATUS_FLAGS(flags) ((flags) & 0x07)
 #define COLATE_UNRESOLVED_EPOCHS(flags) ((int)((unsigned)(flags) >> 8))
 
-/* compiled limits of the EM kernel: one epoch / one age bin per thread of a 256-thread workgroup */
-#define COLATE_MAX_EPOCHS 256
+/* compiled limits of the EM kernel: up to 16 epochs per lane of a 64-lane wave (the reference builds any number of epochs,
+ * coal.cpp:3551-3632: `--bins 3,7,0.01` gives 404; beyond 256 a slower instantiation runs), one age bin per thread */
+#define COLATE_MAX_EPOCHS 1024
 #define COLATE_MAX_AGE_BINS 256
 
 /* reference defaults (coal.cpp:3656, 3822, 3798-3803, 3636) */

@@ -61,9 +61,9 @@ def age_grid():
 
 
 def epochs_from_bins(bins, age=0.0, ypg=28.0):
-    ep = np.zeros(512)
+    ep = np.zeros(2048)
     en = c_int(0)
-    n = O.oracle_epochs_from_bins(bins.encode(), age, ypg, P(ep), 512, ctypes.byref(en))
+    n = O.oracle_epochs_from_bins(bins.encode(), age, ypg, P(ep), 2048, ctypes.byref(en))
     assert n > 0
     return ep[:n].copy(), en.value
 

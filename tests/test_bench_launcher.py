@@ -36,6 +36,14 @@ def test_dry_run_two_ranks_gloo(extra, total, rank0):
         assert key in d
 
 
+def test_dry_run_pairs_two_ranks_gloo():
+    """`--pairs P --replicates B` (BASELINE configs[4]): P x B rows sharded over the ranks, each rank builds only the pairs its rows
+    belong to (3 pairs x 5 replicates over 2 ranks cut inside pair 1), one all-gather."""
+    d = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--pairs", "3", "--replicates", "5"], COLATE_BENCH_DRY="1")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["pairs"] == 3 and d["config"]["replicates_per_pair"] == 5
+    assert d["config"]["replicates_total"] == 15 and d["config"]["replicates_rank0"] == 8 and d["config"]["em_iterations_mean"] == 1001.0
+
+
 def test_dry_run_one_rank_needs_no_launcher():
     d = _run(["--steps", "1", "--warmup", "0", "--replicates", "3"], COLATE_BENCH_DRY="1")
     assert d["n_gpus"] == 1 and d["config"]["replicates_total"] == 3
@@ -67,6 +75,21 @@ def test_two_ranks_share_one_gpu_over_gloo_and_match_one_rank():
     assert strong["n_gpus"] == 2 and strong["scaling"] == "strong"
     assert strong["config"]["replicates_total"] == 13 and strong["config"]["replicates_rank0"] == 7
     assert strong["config"]["em_iterations_mean"] >= 1001
+
+
+@pytest.mark.gpu
+def test_pairs_shape_and_other_configs_on_the_gpu():
+    """The pairs workload as the headline (bootstrap kernel + EM kernel per pass, per-row epochs) with its `other_configs`, and two
+    ranks sharing the GPU over gloo: the rows arrive from both ranks."""
+    common = ["--steps", "1", "--warmup", "1", "--passes-per-step", "2", "--no-cpu-baseline", "--no-host-path", "--no-cxx-rccl-check"]
+    one = _run(common + ["--pairs", "6", "--replicates", "4"])
+    assert one["value"] > 0 and one["config"]["replicates_total"] == 24 and one["config"]["status_flags_nonzero"] == 0
+    assert one["roofline"]["bootstrap_kernel"]["kernel_ms"] > 0 and one["roofline"]["kernel_ms"] > 0
+    names = [o["config"] for o in one["other_configs"]]
+    assert len(names) == 4 and all(o["value"] > 0 and o["status_flags_nonzero"] == 0 for o in one["other_configs"]), names
+    two = _run(common + ["--gpus", "2", "--pairs", "6", "--replicates", "4", "--no-other-configs"], COLATE_BENCH_BACKEND="gloo")
+    assert two["n_gpus"] == 2 and two["config"]["replicates_total"] == 24 and two["config"]["em_iterations_mean"] >= 1001
+    assert two["config"]["status_flags_nonzero"] == 0
 
 
 @pytest.mark.gpu

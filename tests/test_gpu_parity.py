@@ -221,3 +221,31 @@ def test_coal_EM_mirror_reference_unit_test(ca):
                 assert np.all(num[b] >= 0) and np.all(den[b] >= 0)
                 assert _rel(num[b], n0).max() < 1e-7
                 assert (np.abs(den[b] - d0) <= _den_tol(d0, ep, 1.0)).all()
+
+
+@pytest.mark.parametrize("bins,E_expect", [("3,7,0.01", 404), ("2,7.95,0.01", 598), ("2,7.99,0.006", 1002)])
+def test_more_than_256_epochs(ca, bins, E_expect):
+    """The reference builds and runs any number of epochs (coal.cpp:3551-3632: `--bins 3,7,0.01` gives 404); so does the drop-in,
+    up to 1024, on the 8- and 16-epochs-per-lane instantiations (csrc/em_kernels_big.hip): full EM runs to the reference's stop
+    rule against the oracle -- iteration counts, log-likelihood, every rate the checker finds pinned -- and one E-step."""
+    from colate_amd import workloads
+
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins(bins)
+    assert ep.size == E_expect
+    csh, cns = workloads.bootstrap_tables(grid, 2, nb=9, scale=1.0)
+    r0, it0, ll0, fl0 = ol.em_batch(grid, csh, cns, ep)
+    r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep)
+    assert (it0 == it1).all() and ((fl0 & 3) == 0).all() and (ca.status_flags(fl1) == 0).all()
+    assert np.allclose(ll1, ll0, rtol=1e-12, atol=0)
+    noise, scaled = ol.rerun_rates(grid, csh, cns, ep)
+    mask = ol.mask_from_reruns(r0, noise + scaled)
+    assert mask.mean() > 0.8, mask.mean()
+    ol.check_rates(r1, fl1, r0, mask, RATE_RTOL)
+    rates = np.exp(np.random.default_rng(E_expect).uniform(np.log(2e-6), np.log(3e-4), (2, ep.size)))
+    N1, D1, l1, f1 = ca.em_estep(grid, csh, cns, ep, rates)
+    for b in range(2):
+        N0, D0, l0, f0 = ol.estep(ep, rates[b], grid, csh[b], cns[b])
+        ok = D0 > 1e-250
+        assert f0 == 0 and f1[b] == 0 and abs(l1[b] / l0 - 1) < 1e-12
+        assert _rel(N1[b][ok], N0[ok]).max() < 1e-9 and _rel(D1[b][ok], D0[ok]).max() < 1e-9

@@ -58,8 +58,8 @@ def test_argument_validation(ca):
     with pytest.raises(ca.ColateError) as e:  # unsorted epochs
         ca.em_batch(grid, one, one, ep[::-1].copy())
     assert e.value.code == -1
-    with pytest.raises(ca.ColateError) as e:  # too many epochs
-        ca.em_batch(grid, one, one, np.arange(300.0))
+    with pytest.raises(ca.ColateError) as e:  # too many epochs (the compiled limit is 1024: 16 per lane of a wave)
+        ca.em_batch(grid, one, one, np.arange(1100.0))
     assert e.value.code == -4
     with pytest.raises(ca.ColateError):  # bad --bins
         ca.epochs_from_bins("3,7")

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where the EM kernel's time goes that is not the steady-state iterations (GPU box): kernel time by events on its stream for
 max_iter = 1, 2, 3, 5, 9, 17, 33, 65, 129, 257, 1001 at B = 100 (min_iter beyond max_iter: no log-likelihood phase), for 23 and 122 epochs.
-The tail model is refreshed in iterations 0, 1, 2, 4, 8, ...: a step of the series contains one refresh more than the one before.
+The tail model is refreshed in iterations 0, 1, 2, 4, 8, ... (from 128 on every 128th with more than 64 epochs): the steady-state
+rate is the slope between max_iter 140 and 250, which contain no refresh; the step from 250 to 262 contains exactly one (at 256).
     gpurun -- python3 tools/fixed_cost.py"""
 import os
 import sys
@@ -33,7 +34,7 @@ for bins in ("3,7,0.2", "2,7.95,0.05"):
     fl = torch.empty(B, dtype=torch.int32, device=dev)
     st = torch.cuda.Stream()
     res = []
-    for mi in (1, 2, 3, 5, 9, 17, 33, 65, 129, 257, 1001):
+    for mi in (1, 2, 3, 5, 9, 17, 33, 65, 129, 140, 250, 262, 1001):
         ts = []
         with torch.cuda.stream(st):
             for rep in range(12):
@@ -44,7 +45,8 @@ for bins in ("3,7,0.2", "2,7.95,0.05"):
                 st.synchronize()
                 ts.append(e0.elapsed_time(e1) * 1e3)
         res.append((mi, float(np.median(ts[3:]))))
-    slope = (res[-1][1] - res[-2][1]) / (res[-1][0] - res[-2][0])
+    t140, t250 = dict(res)[140], dict(res)[250]
+    slope = (t250 - t140) / 110.0
     print("%s (E = %d, B = %d): steady-state iteration %.4f us" % (bins, E, B, slope))
     prev = None
     for mi, t in res:

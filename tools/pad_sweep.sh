@@ -13,7 +13,7 @@ for n in 0 1 2 3 4 5 6 7; do
   /opt/rocm/bin/hipcc $F "$@" -DCOLATE_LOOP_PAD=$n -c em_kernels.hip -o /tmp/em_$prefix$n.o &
   wait
   mkdir -p ../lib_$prefix$n
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib_$prefix$n/libcolate_amd.so /tmp/em_$prefix$n.o /tmp/ilp_$prefix$n.o \
-    bootstrap_kernel.o colate_api.o colate_comm.o mut_host.o mut_driver.o -lz -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib_$prefix$n/libcolate_amd.so /tmp/em_$prefix$n.o /tmp/ilp_$prefix$n.o em_kernels_big.o \
+    bootstrap_kernel.o colate_api.o colate_comm.o mut_host.o mut_driver.o mut_pairs.o -lz -ldl
   echo "built lib_$prefix$n"
 done

@@ -9,6 +9,11 @@
 //   2  per (bin, epoch): integ = s_b H((x_be - D_b)/s_b), H(z) = phi(z) + z Phi(z); D_b = mass of the terms the
 //      reference's log-sum-exp fold absorbs (term / running sum < ulp(Z_b)/2), s_b^2 = chain + fold rounding variance
 //   3  per (bin, epoch): integ = max(0, x_be - D_b)  (no noise part)
+//   4  per epoch, aggregated noise scale (an early candidate)
+//   5  round 3's kernel: max(x_be - D_b, 0.4 s_b) through cut sets, D_b / s_b from the cheap per-bin estimates, refreshed sparsely
+//   6  round 4's kernel: model 2's form s_b H((x_be - D_b) / s_b) with model 5's per-bin D_b, s_b and refresh schedule
+//   7  as 6 with H replaced by a quadratic blend
+//   8  as 6, the held correction linearised in S_{e+1}: R_e = R0_e + dR/dS (S_{e+1} - S0_e) between refreshes
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,11 +35,11 @@ static double half_ulp(double z) {  // half the spacing of doubles at |z|
 }
 
 struct M5Bin { int b, k; double c, cs_a, xk; };
-static int REFRESH = 32, EARLY = 0, POW2 = 0;
+static int REFRESH = 32, EARLY = 0, POW2 = 0, SHRES = 0, SKIP12 = 0;
 struct Fact {
   int E, A, model, iter_no = 0;
   std::vector<M5Bin> m5_bins;
-  std::vector<double> R5;
+  std::vector<double> R5, R5_1, R5_S0;
   std::vector<double> t, grid, csh, cns;
   std::vector<int> kb;
   std::vector<double> N, D;
@@ -98,7 +103,7 @@ struct Fact {
             double nk = pn * rr, dk = bn * rr - t[k] * nk + dt[k] * (1.0 - nk);
             h[k] += c * (u * rr); hc[k] += c; hN[k] += c * nk; hD[k] += c * std::fmax(dk, 0.0);
             if (model == 4) ThetaAt[k] += c * half_ulp(-ck2 + std::log(Sig));
-            if (model == 5) m5_bins.push_back({b, k, c, ck2, lk * dt[k]});
+            if (model >= 5) m5_bins.push_back({b, k, c, ck2, lk * dt[k]});
             if (model == 2 || model == 3) {
               // the reference's fold for this bin: terms n_k = pn, n_e = xprev * p_e (e > k), running sum -> 1; a term is
               // absorbed when term / running sum < ulp(nc)/2 with nc = log(running sum) - cs(a)
@@ -143,12 +148,12 @@ struct Fact {
       }
     }
     // ---- model 5 = the algorithm of the HIP kernel (refresh every REFRESH iterations, R5 held in between)
-    if (model == 5 && (POW2 ? (iter_no < EARLY || ((iter_no & (iter_no - 1)) == 0) || (iter_no % REFRESH) == 0) : ((iter_no % REFRESH) == 0 || iter_no < EARLY))) {
+    if (model >= 5 && !(SKIP12 && (iter_no == 1 || iter_no == 2)) && (POW2 ? (iter_no < EARLY || ((iter_no & (iter_no - 1)) == 0) || (iter_no % REFRESH) == 0) : ((iter_no % REFRESH) == 0 || iter_no < EARLY))) {
       int k_old = -1;
       for (auto& bn : m5_bins) if (bn.k > k_old) k_old = bn.k;
       // epochs whose fold term can be absorbed by some bin / whose survival can be below some bin's threshold
       const int nb = (int)m5_bins.size();
-      std::vector<double> tau(nb), cq(nb), cm(nb);
+      std::vector<double> tau(nb), cq(nb), cm(nb), Dbv(nb), sbv(nb), mv(nb);
       double PDtot = 0;
       for (int i = 0; i < nb; i++) {
         const auto& bn = m5_bins[i];
@@ -166,13 +171,14 @@ struct Fact {
         const double sc2 = std::ldexp(1.0, -108) / 3.0 * nhalf;
         const double rho = 0.4 * std::sqrt(sc2 + th * th * nfold / 3.0);
         tau[i] = (Db + rho) / m;
+        Dbv[i] = Db, sbv[i] = rho / 0.4, mv[i] = m;
         cq[i] = bn.c * (rho + Db), cm[i] = bn.c * m;
         PDtot += bn.c * Db;
       }
       for (int i = nb - 2; i >= 0; i--) tau[i] = std::fmax(tau[i], tau[i + 1]);  // suffix max: the cut set is a prefix
       std::vector<double> PQ(nb + 1, 0), PM(nb + 1, 0);
       for (int i = 0; i < nb; i++) PQ[i + 1] = PQ[i] + cq[i], PM[i + 1] = PM[i] + cm[i];
-      R5.assign(E, 0.0);
+      R5.assign(E, 0.0), R5_1.assign(E, 0.0), R5_S0.assign(E, 0.0);
       for (int e = 0; e < E - 1; e++) {
         int lo_e = 0;  // bins of earlier epochs
         while (lo_e < nb && m5_bins[lo_e].k < e) lo_e++;
@@ -180,6 +186,18 @@ struct Fact {
         while (bs < nb && tau[bs] > S[e + 1]) bs++;
         if (bs > lo_e) bs = lo_e;
         R5[e] = PQ[bs] - S[e + 1] * PM[bs] - (e > k_old ? PDtot : 0.0);
+        if (model >= 6) {  // per (bin, epoch): c_b (s_b H((x_be - D_b) / s_b) - x_be), D_b and s_b as the kernel computes them
+          double r = 0, r1 = 0;
+          for (int i = 0; i < lo_e; i++) {
+            const double x = S[e + 1] * mv[i], z = (x - Dbv[i]) / sbv[i];
+            const double Hq = z >= 2 ? z : (z <= -2 ? 0.0 : (z + 2) * (z + 2) / 8);
+            r += m5_bins[i].c * (sbv[i] * (model != 7 ? Hfun(z) : Hq) - x);
+            // d/dS of c s (H(z) - x / s) = c m (Phi(z) - 1) = -c m Q(z)
+            r1 -= m5_bins[i].c * mv[i] * 0.5 * std::erfc(z / std::sqrt(2.0));
+          }
+          R5[e] = r;
+          R5_1[e] = r1, R5_S0[e] = S[e + 1];
+        }
       }
     }
     m5_bins.clear();
@@ -193,7 +211,7 @@ struct Fact {
       if (e < E - 1) {
         double integ_ns = G[e + 1] * (q[e] * T[e]);
         if (model == 2 || model == 3) integ_ns = std::fmax(integ_ns + Icorr[e], 0.0);
-        if (model == 5) integ_ns = std::fmax(integ_ns + R5[e], 0.0);
+        if (model >= 5) integ_ns = std::fmax(integ_ns + R5[e] + (model == 8 ? R5_1[e] * (S[e + 1] - R5_S0[e]) : 0.0), 0.0);
         if (model == 4) {
           double Th = 0, Cp = 0;
           for (int j = 0; j < e; j++) Th += ThetaAt[j], Cp += hc[j];  // bins of earlier epochs
@@ -208,6 +226,10 @@ struct Fact {
         D[e] = (std::fmax(VW[e] * rs + dt[e] * std::fmax(cs_ - PW[e + 1] * rs, 0.0), 0.0) + gV[e]) +
                (std::fmax(dt[e] * cn + ((beta[e] - t[e] * p[e]) * T[e] + dt[e] * integ_ns), 0.0) + hD[e]);
         if (model == 1) D[e] += dt[e] * (4.0e-17 * call);
+        // the shared kind's mean residue as the kernel adds it: SHRES=1 round 3 (every epoch, all shared counts), SHRES=2 round 4
+        // (only the shared bins whose own chain reaches epoch e: k_b >= e -- coal_EM.cpp:266-278 stops at the bin's epoch)
+        if (model >= 5 && SHRES == 1) D[e] += dt[e] * (4.0e-17 * CS[0]);
+        if (model >= 5 && SHRES == 2) D[e] += dt[e] * (4.0e-17 * CS[e]);
       } else
         D[e] = gV[e] + (beta[e] - t[e] * p[e]) * T[e] + hD[e];
     }
@@ -215,7 +237,7 @@ struct Fact {
   int em(std::vector<double>& rates) {
     double l = -INFINITY, prev;
     int iter;
-    R5.assign(E, 0.0);
+    R5.assign(E, 0.0), R5_1.assign(E, 0.0), R5_S0.assign(E, 0.0);
     for (iter = 0; iter < 100000; iter++) {
       prev = l;
       iter_no = iter;
@@ -258,7 +280,9 @@ int main(int argc, char** argv) {
   if (getenv("REFRESH")) REFRESH = atoi(getenv("REFRESH"));
   if (getenv("EARLY")) EARLY = atoi(getenv("EARLY"));
   if (getenv("POW2")) POW2 = atoi(getenv("POW2"));
-  for (int m = 0; m <= 5; m++) {
+  if (getenv("SHRES")) SHRES = atoi(getenv("SHRES"));
+  if (getenv("SKIP12")) SKIP12 = atoi(getenv("SKIP12"));
+  for (int m = 0; m <= 8; m++) {
     F.model = m;
     std::vector<double> rates(E, 1.0 / 20000.0);
     its.push_back(F.em(rates));
@@ -266,7 +290,7 @@ int main(int argc, char** argv) {
     if (m == 2) { dbg_cD = dbg_cth = dbg_cs = dbg_csc = 0; F.estep(rates); printf("model 2 at the fixed point: sum c D_b / sum c theta_b = %.3f, sum c s_b / sum c theta_b = %.3f, sum c s_chain / sum c = %.3e, sum c theta / sum c = %.3e\n", dbg_cD / dbg_cth, dbg_cs / dbg_cth, dbg_csc, dbg_cth); }
     res.push_back(rates);
   }
-  printf("iterations: %d %d %d %d %d %d\n", its[0], its[1], its[2], its[3], its[4], its[5]);
-  for (int e = e_lo; e < E; e++) printf("%d %.10g %.10g %.10g %.10g %.10g %.10g\n", e, res[0][e], res[1][e], res[2][e], res[3][e], res[4][e], res[5][e]);
+  printf("iterations: %d %d %d %d %d %d %d %d %d\n", its[0], its[1], its[2], its[3], its[4], its[5], its[6], its[7], its[8]);
+  for (int e = e_lo; e < E; e++) printf("%d %.10g %.10g %.10g %.10g %.10g %.10g %.10g %.10g %.10g\n", e, res[0][e], res[1][e], res[2][e], res[3][e], res[4][e], res[5][e], res[6][e], res[7][e], res[8][e]);
   return 0;
 }
