@@ -562,7 +562,7 @@ def run_rank(args):
     passes = args.passes_per_step
     if passes <= 0:
         est = run.estimate()
-        passes = 1 if dry else max(1, int(np.ceil(TIMED_REGION_S / (args.steps * est))))
+        passes = 1 if dry else max(1, int(np.ceil(1.05 * TIMED_REGION_S / (args.steps * est))))  # (5 % on top: the estimate includes first-touch effects)
         if world > 1:
             t = torch.tensor([passes], dtype=torch.int64, device=cd.collective_device(dist))
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

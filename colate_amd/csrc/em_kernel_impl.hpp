@@ -522,7 +522,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
 #pragma unroll
     for (int j = 0; j < 8; j++) v[j] = s_cnt[role * APZ + b + j];
 #pragma unroll
-    for (int j = 0; j < 8; j++) c_all += v[j];
+    for (int j = 0; j < 8; j++) c_all += (b + j < nzhi) ? v[j] : 0.0;  // (see c_later below: never past the data)
   }
   COLATE_PSTAMP(5)
   // role A: dt_e * residue of the shared bins that reach the epoch (set with the bin ranges below).  Role B: the tail
@@ -530,7 +530,11 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   // (role B, more than 64 epochs -- where deep tails are the rule --: R_e is held as a linear function of the exact mass X_e = q_e T_e
   // of the epoch (proportional to S_{e+1}), integ = eta_s X_e + eta_e with eta_s = 1 + dR_e / dX_e, between two refreshes that are up to 128 iterations apart; up to 64 epochs: as a constant, refreshed every 32nd
   // iteration while some epoch is in transition -- with --bins 3,7,0.2 none ever is --, no instruction in the iteration)
+#ifdef COLATE_TAIL_CONST_HOLD  // (A/B switch: the correction held as a constant at every epoch count)
+  constexpr bool kLinearHold = false;
+#else
   constexpr bool kLinearHold = (NCH >= 2);
+#endif
   double eta_e[NCH], eta_s[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; c++) eta_e[c] = 0.0, eta_s[c] = 1.0;
@@ -578,8 +582,10 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
         for (int j = 0; j < 8; j++) v[j] = s_cnt[role * APZ + b + j];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          c_later += (ep_on[c] && b + j >= hi) ? v[j] : 0.0;
-          c_ge += (ep_on[c] && b + j >= lo) ? v[j] : 0.0;
+          // (b + j < nzhi: the last round of eight may reach past the row's zero padding -- up to AP + 1 -- into what lies behind
+          // it in LDS, e.g. another launch's log-likelihood partials: round 4's fuzz, 46 cases, once the walk started at lo)
+          c_later += (ep_on[c] && b + j >= hi && b + j < nzhi) ? v[j] : 0.0;
+          c_ge += (ep_on[c] && b + j >= lo && b + j < nzhi) ? v[j] : 0.0;
         }
       }
     }

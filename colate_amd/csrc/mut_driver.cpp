@@ -1107,22 +1107,35 @@ int run_mut(const Options& opt) {
       if (opt.has("target_mask")) tmask.push_back(opt.get("target_mask"));
       if (opt.has("reference_mask")) rmask.push_back(opt.get("reference_mask"));
     }
-    BlockTables tab;
-    const int nb = fill_tables_from_tmp(names, mut_files, opt.get("target_tmp"),
-                                        opt.get("reference_tmp"), tmask, rmask, C, rng,
-                                        num_bases_per_block, A, tab);
+    // Without masks the pair goes through the engine of the batched front end (mut_pairs.cpp) as a list of one: every .mut file
+    // parsed in parallel, the .colate.in files mapped, the SNP walk on one thread and the age sampling of the genome blocks on
+    // all the others, exact table-driven age bins -- the same tables bit for bit (22 x 1M rows: 3.3 -> 0.x s of table fill,
+    // profiles/r04/bench/e2e_large.txt).  With masks (and with COLATE_THREADS=1 or COLATE_SINGLE_FEEDER=1) the single-pair
+    // feeder below, which is also what the engine falls back to.
+    int nb = -1;
+    const char* thr_env = std::getenv("COLATE_THREADS");
+    if (tmask.empty() && rmask.empty() && !std::getenv("COLATE_SINGLE_FEEDER") && !(thr_env && std::atoi(thr_env) <= 1)) {
+      for (size_t chr = 0; chr < mut_files.size(); chr++) std::cerr << "parsing CHR: " << chr + 1 << " / " << mut_files.size() << std::endl;
+      nb = fill_single_pair(opt, opt.get("target_tmp"), opt.get("reference_tmp"), seed, A, fsh, fns, fshe, fnse, rng);
+    }
+    if (nb < 0) {
+      BlockTables tab;
+      nb = fill_tables_from_tmp(names, mut_files, opt.get("target_tmp"), opt.get("reference_tmp"), tmask, rmask, C, rng,
+                                num_bases_per_block, A, tab);
+      // block bootstrap + F redistribution (coal.cpp:3326-3451) on flat [nb][A] tables
+      const int nbp = nb > 0 ? nb : 0;
+      fsh.resize((size_t)nbp * A), fns.resize((size_t)nbp * A), fshe.resize((size_t)nbp * A), fnse.resize((size_t)nbp * A);
+      for (int j = 0; j < nbp; j++) {
+        std::copy(tab.sh[j].begin(), tab.sh[j].end(), fsh.begin() + (size_t)j * A);
+        std::copy(tab.ns[j].begin(), tab.ns[j].end(), fns.begin() + (size_t)j * A);
+        std::copy(tab.sh_emp[j].begin(), tab.sh_emp[j].end(), fshe.begin() + (size_t)j * A);
+        std::copy(tab.ns_emp[j].begin(), tab.ns_emp[j].end(), fnse.begin() + (size_t)j * A);
+      }
+    }
     std::cerr << "Number of blocks: " << nb << std::endl;
     if (nb < 1) {
       std::cerr << "Error: no genome blocks were read." << std::endl;
       return 1;
-    }
-    // block bootstrap + F redistribution (coal.cpp:3326-3451) on flat [nb][A] tables
-    fsh.resize((size_t)nb * A), fns.resize((size_t)nb * A), fshe.resize((size_t)nb * A), fnse.resize((size_t)nb * A);
-    for (int j = 0; j < nb; j++) {
-      std::copy(tab.sh[j].begin(), tab.sh[j].end(), fsh.begin() + (size_t)j * A);
-      std::copy(tab.ns[j].begin(), tab.ns[j].end(), fns.begin() + (size_t)j * A);
-      std::copy(tab.sh_emp[j].begin(), tab.sh_emp[j].end(), fshe.begin() + (size_t)j * A);
-      std::copy(tab.ns_emp[j].begin(), tab.ns_emp[j].end(), fnse.begin() + (size_t)j * A);
     }
     num_blocks = nb;
     csh.assign((size_t)B * A, 0.0);

@@ -155,5 +155,10 @@ void print_usage_footer();  // "CPU Time spent: ...; Max Memory usage: ..." (coa
 
 // mut_pairs.cpp
 int run_mut_pairs(const Options& opt);
+// One pair through the engine of the batched front end: the flat [nb][A] tables and the generator as the fill leaves it.
+// Returns the number of genome blocks, or -1 if the engine cannot be used here (the caller then runs fill_tables_from_tmp).
+int fill_single_pair(const Options& opt, const std::string& target, const std::string& reference, int seed, int A,
+                     std::vector<double>& sh, std::vector<double>& ns, std::vector<double>& she, std::vector<double>& nse,
+                     std::mt19937& rng);
 
 }  // namespace colate_drv

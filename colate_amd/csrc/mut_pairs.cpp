@@ -847,6 +847,20 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
 
 }  // namespace
 
+int fill_single_pair(const Options& opt, const std::string& target, const std::string& reference, int seed, int A,
+                     std::vector<double>& sh, std::vector<double>& ns, std::vector<double>& she, std::vector<double>& nse,
+                     std::mt19937& rng) {
+  if (!bulk_stream_ok((unsigned)seed)) return -1;  // (fill_pairs would run the single-pair feeder itself: let the caller do it)
+  std::vector<PairSpec> one(1);
+  one[0].target = target, one[0].reference = reference;
+  std::vector<PairTables> tabs;
+  if (!fill_pairs(opt, one, {0}, seed, A, tabs)) return -1;
+  PairTables& pt = tabs[0];
+  sh = std::move(pt.sh), ns = std::move(pt.ns), she = std::move(pt.she), nse = std::move(pt.nse);
+  rng = pt.rng;
+  return pt.nb;
+}
+
 int run_mut_pairs(const Options& opt) {
   if (!opt.has("mut") || !opt.has("bins")) {
     std::cerr << "Error: --pairs needs --mut and --bins (and optionally --chr, --num_bootstraps, --seed)." << std::endl;

@@ -248,4 +248,6 @@ def test_more_than_256_epochs(ca, bins, E_expect):
         N0, D0, l0, f0 = ol.estep(ep, rates[b], grid, csh[b], cns[b])
         ok = D0 > 1e-250
         assert f0 == 0 and f1[b] == 0 and abs(l1[b] / l0 - 1) < 1e-12
-        assert _rel(N1[b][ok], N0[ok]).max() < 1e-9 and _rel(D1[b][ok], D0[ok]).max() < 1e-9
+        # (numerators to rounding; denominators to 1e-7: in the last epochs with data they hold the reference's integ residue,
+        # which the kernel models -- DESIGN.md section 6 -- instead of reproducing bit for bit)
+        assert _rel(N1[b][ok], N0[ok]).max() < 1e-9 and _rel(D1[b][ok], D0[ok]).max() < 1e-7

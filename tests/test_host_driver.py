@@ -207,8 +207,10 @@ def test_pairs_mode_counts_equal_separate_runs(tmp_path):
     # every input file is read once, whatever number of pairs it takes part in (here: both files in both pairs)
     assert "3 .mut files" in r.stderr.decode() and "2 .colate.in files" in r.stderr.decode(), r.stderr.decode()[-800:]
     for tgt, ref, out, ta, ra in specs:
+        # (COLATE_SINGLE_FEEDER=1: the pair alone through the single-pair feeder, not through the engine of the batched front end)
         r = _run_cli(common + ["--target_tmp", tgt, "--reference_tmp", ref, "--target_age", ta, "--reference_age", ra,
-                               "-o", out + "_single", "--counts_out", out + "_single.counts", "--counts_only"], str(tmp_path))
+                               "-o", out + "_single", "--counts_out", out + "_single.counts", "--counts_only"], str(tmp_path),
+                     env=dict(os.environ, COLATE_SINGLE_FEEDER="1"))
         assert r.returncode == 0, r.stderr.decode()[-800:]
         assert (tmp_path / (out + ".counts")).read_text() == (tmp_path / (out + "_single.counts")).read_text()
 
@@ -445,15 +447,19 @@ def test_ranks_refused_once_the_process_has_used_the_device(ca, tmp_path):
     assert r.returncode == 1 and "must run before this process first uses a GPU" in r.stderr, (r.returncode, r.stderr)
 
 
-def _counts(tmp_path, threads, extra=()):
+def _counts(tmp_path, threads, extra=(), single_feeder=False):
+    """single_feeder: the pair through the single-pair feeder of mut_driver.cpp (reader threads, uniform-stream thread, sampling
+    workers) instead of the engine of the batched front end (mut_pairs.cpp), which is what a pair without masks takes by default."""
     env = dict(os.environ, COLATE_THREADS=str(threads), COLATE_TIMING="1")
-    out = f"c{threads}"
+    if single_feeder:
+        env["COLATE_SINGLE_FEEDER"] = "1"
+    out = f"c{threads}{'s' if single_feeder else ''}"
     r = subprocess.run([CLI, "--mode", "mut", "--mut", "P", "--target_tmp", "T.colate.in", "--reference_tmp", "R.colate.in", "--chr",
                         "chr.txt", "--bins", "3,7,0.2", "--seed", "11", "--num_bootstraps", "7", "--counts_only", "--counts_out",
                         out + ".counts", "-o", out] + list(extra), cwd=str(tmp_path), capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-500:]
     assert "Timing: parse_mut" in r.stderr
-    _counts.redone = "repeated sequentially" in r.stderr
+    _counts.redone = "repeated sequentially" in r.stderr or "1 pair(s) redone sequentially" in r.stderr
     return (tmp_path / (out + ".counts")).read_text()
 
 
@@ -463,9 +469,11 @@ def test_threaded_table_fill_is_bit_identical_to_sequential(tmp_path):
     import synth_files
 
     synth_files.write_inputs(str(tmp_path), chroms=("1", "2", "3"), snps_per_chr=4000, seed=3, gz=True)
-    threaded = _counts(tmp_path, 8)
+    threaded = _counts(tmp_path, 8, single_feeder=True)
     assert not _counts.redone
     assert threaded == _counts(tmp_path, 1)
+    assert threaded == _counts(tmp_path, 8)  # ... and so does the engine of the batched front end with a list of one pair
+    assert not _counts.redone
 
 
 def test_threaded_table_fill_redoes_sequentially_when_a_sample_is_redrawn(tmp_path):
@@ -488,9 +496,11 @@ def test_threaded_table_fill_redoes_sequentially_when_a_sample_is_redrawn(tmp_pa
     assert n_changed == 40
     with gzip.open(p, "wt") as g:
         g.write("\n".join(lines))
-    threaded = _counts(tmp_path, 8)
+    threaded = _counts(tmp_path, 8, single_feeder=True)
     assert _counts.redone  # (the threaded pass gave up ...)
     assert threaded == _counts(tmp_path, 1)  # (... and the repeat is the sequential result)
+    assert threaded == _counts(tmp_path, 8)  # (the engine of the batched front end notices too and hands the pair to the feeder)
+    assert _counts.redone
 
 
 def test_malformed_mut_line_is_reported_from_the_reader_thread(tmp_path):

@@ -116,7 +116,7 @@ def test_pairs_front_end_clean_and_equal_to_single_runs(tmp_path):
     for tgt, ref, out, ta, ra in specs[:4]:
         subprocess.check_call([cli] + common + ["--target_tmp", tgt, "--reference_tmp", ref, "--target_age", ta, "--reference_age", ra,
                                                  "-o", out + "_single", "--counts_out", out + "_single.counts", "--counts_only"],
-                              cwd=str(tmp_path), stderr=subprocess.DEVNULL)
+                              cwd=str(tmp_path), stderr=subprocess.DEVNULL, env=dict(os.environ, COLATE_SINGLE_FEEDER="1"))
         expected[out] = (tmp_path / (out + "_single.counts")).read_text()
     for exe, threads in ((ASAN_CLI, "3"), (TSAN_CLI, "1"), (TSAN_CLI, "3"), (TSAN_CLI, "8")):
         r, err = _run(exe, common + ["--pairs", "pairs.txt", "--counts_only"], str(tmp_path), COLATE_THREADS=threads,
@@ -138,5 +138,6 @@ def test_pairs_front_end_clean_and_equal_to_single_runs(tmp_path):
     r, err = _run(ASAN_CLI, common + ["--pairs", "pairs3.txt", "--counts_only"], str(tmp_path))
     assert r.returncode == 0, err[-800:]
     subprocess.check_call([cli] + common + ["--target_tmp", "trunc.colate.in", "--reference_tmp", "R.colate.in", "-o", "p5_single",
-                                             "--counts_out", "p5_single.counts", "--counts_only"], cwd=str(tmp_path), stderr=subprocess.DEVNULL)
+                                             "--counts_out", "p5_single.counts", "--counts_only"], cwd=str(tmp_path), stderr=subprocess.DEVNULL,
+                          env=dict(os.environ, COLATE_SINGLE_FEEDER="1"))
     assert (tmp_path / "p5.counts").read_text() == (tmp_path / "p5_single.counts").read_text()
