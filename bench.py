@@ -283,8 +283,8 @@ def cxx_rccl_check(colate_amd, nranks, grid, csh, cns, epochs, bins):
 
 
 # --------------------------------------------------------------------------------------------- PMC records and their validity
-KERNEL_SOURCES = ("em_kernel_impl.hpp", "em_math.hpp", "em_kernels.h", "em_kernels.hip", "em_kernels_ilp.hip", "bootstrap_kernel.hip",
-                  "Makefile")
+KERNEL_SOURCES = ("em_kernel_impl.hpp", "em_math.hpp", "em_kernels.h", "em_kernels.hip", "em_kernels_ilp.hip", "em_kernels_big.hip",
+                  "bootstrap_kernel.hip")
 
 
 def kernel_source_sha16():

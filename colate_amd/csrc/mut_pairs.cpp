@@ -19,6 +19,7 @@
 //   * `--ranks N`: the rows (pair, replicate) are sharded over N processes, one per GPU; a rank fills only the pairs its
 //     rows belong to, and one RCCL all-gather per launch returns every rank all results.
 #include <fcntl.h>
+#include <immintrin.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -430,6 +431,11 @@ class FastBin {
     ok_ = ok_ && agrees(0.0) && agrees(1e-310) && agrees(0.05) && agrees(1e9);
   }
   bool ok() const { return ok_; }
+  int bins() const { return A_; }
+  // lower / upper edge of the guard band around step k (k = 1 .. A; [0] = -inf, [A + 1] = +inf): bin(x) = #{k : hi(k) <= x} for
+  // every x outside all bands
+  const double* guard_lo() const { return lo_.data(); }
+  const double* guard_hi() const { return hi_.data(); }
   // age_bin_index(x, C), with every value >= A returned as A
   int operator()(double x) const {
     if (!ok_) return std::min(f(x), A_);
@@ -474,6 +480,90 @@ class FastBin {
   bool ok_ = false;
 };
 
+// ------------------------------------------------------------------ the 100 sampled ages of one SNP, eight (four) at a time
+// All 100 ages of a SNP lie in [age_begin, age_end], a handful of age bins (age_end <= 2.5 age_begin: ten bins of e^0.1): the bin of
+// a sample is b_lo + the number of steps k in (b_lo, b_hi + 1] at or below it -- one vector compare per step instead of a table
+// walk per sample.  Exact by the same argument as FastBin: the steps are counted twice, against the lower and against the upper
+// edge of their guard bands; the counts differ iff some sample lies inside a band, and then (as when the range is too wide, or
+// touches the end of the grid) the SNP goes through the scalar code.  x = u * span + begin is formed by a separate multiply and add,
+// like the reference's (no fused multiply-add anywhere).  Returns false = "use the scalar path"; else bins[0..99] are set.
+using BinSnpFn = bool (*)(const double* u, double span, double begin, const double* lo, const double* hi, int b_lo, int K, int* bins);
+
+__attribute__((target("avx512f"))) bool bin_snp_avx512(const double* u, double span, double begin, const double* lo, const double* hi,
+                                                        int b_lo, int K, int* bins) {
+  const __m512d vs = _mm512_set1_pd(span), vb = _mm512_set1_pd(begin);
+  const __m512i one = _mm512_set1_epi64(1);
+  __mmask8 bad = 0;
+  for (int i = 0; i < 104; i += 8) {  // (u is padded to 104 values)
+    const __m512d x = _mm512_add_pd(_mm512_mul_pd(_mm512_loadu_pd(u + i), vs), vb);
+    __m512i c_lo = _mm512_setzero_si512(), c_hi = _mm512_setzero_si512();
+    for (int j = 1; j <= K; j++) {
+      c_lo = _mm512_mask_add_epi64(c_lo, _mm512_cmp_pd_mask(x, _mm512_set1_pd(lo[b_lo + j]), _CMP_GE_OQ), c_lo, one);
+      c_hi = _mm512_mask_add_epi64(c_hi, _mm512_cmp_pd_mask(x, _mm512_set1_pd(hi[b_lo + j]), _CMP_GE_OQ), c_hi, one);
+    }
+    bad |= _mm512_cmpneq_epi64_mask(c_lo, c_hi);
+    bad |= _mm512_cmp_pd_mask(x, _mm512_set1_pd(hi[b_lo]), _CMP_LT_OQ);  // inside (or below) the band of the step the range starts at
+    _mm256_storeu_si256(reinterpret_cast<__m256i*>(bins + i), _mm512_cvtepi64_epi32(_mm512_add_epi64(c_hi, _mm512_set1_epi64(b_lo))));
+  }
+  return bad == 0;
+}
+
+__attribute__((target("avx2"))) bool bin_snp_avx2(const double* u, double span, double begin, const double* lo, const double* hi, int b_lo,
+                                                  int K, int* bins) {
+  const __m256d vs = _mm256_set1_pd(span), vb = _mm256_set1_pd(begin);
+  __m256i bad = _mm256_setzero_si256();
+  for (int i = 0; i < 100; i += 4) {
+    const __m256d x = _mm256_add_pd(_mm256_mul_pd(_mm256_loadu_pd(u + i), vs), vb);
+    __m256i c_lo = _mm256_setzero_si256(), c_hi = _mm256_setzero_si256();
+    for (int j = 1; j <= K; j++) {  // (a true compare is all ones = -1: subtracting it adds one)
+      c_lo = _mm256_sub_epi64(c_lo, _mm256_castpd_si256(_mm256_cmp_pd(x, _mm256_set1_pd(lo[b_lo + j]), _CMP_GE_OQ)));
+      c_hi = _mm256_sub_epi64(c_hi, _mm256_castpd_si256(_mm256_cmp_pd(x, _mm256_set1_pd(hi[b_lo + j]), _CMP_GE_OQ)));
+    }
+    bad = _mm256_or_si256(bad, _mm256_xor_si256(c_lo, c_hi));
+    bad = _mm256_or_si256(bad, _mm256_castpd_si256(_mm256_cmp_pd(x, _mm256_set1_pd(hi[b_lo]), _CMP_LT_OQ)));
+    alignas(32) long long c[4];
+    _mm256_store_si256(reinterpret_cast<__m256i*>(c), c_hi);
+    bins[i] = b_lo + (int)c[0], bins[i + 1] = b_lo + (int)c[1], bins[i + 2] = b_lo + (int)c[2], bins[i + 3] = b_lo + (int)c[3];
+  }
+  return _mm256_testz_si256(bad, bad) != 0;
+}
+
+// The additions themselves: bin j of the SNP's range gets cnt[j] additions of the SNP's weight, one after the other (what the
+// sample-by-sample loop does to it, in the same order).  Up to sixteen bins side by side in two vectors per table, a masked add per
+// step: sixteen chains of dependent additions run at once instead of one after the other.  (Needs b_lo + 16 <= A.)
+using AddSnpFn = void (*)(double* sh, double* ns, int b_lo, const int* cnt, double w_sh, double w_ns);
+
+__attribute__((target("avx512f"))) void add_snp_avx512(double* sh, double* ns, int b_lo, const int* cnt, double w_sh, double w_ns) {
+  __m512d s0 = _mm512_loadu_pd(sh + b_lo), s1 = _mm512_loadu_pd(sh + b_lo + 8);
+  __m512d n0 = _mm512_loadu_pd(ns + b_lo), n1 = _mm512_loadu_pd(ns + b_lo + 8);
+  const __m512i c0 = _mm512_cvtepi32_epi64(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(cnt)));
+  const __m512i c1 = _mm512_cvtepi32_epi64(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(cnt + 8)));
+  const __m512d ws = _mm512_set1_pd(w_sh), wn = _mm512_set1_pd(w_ns);
+  int most = 0;
+  for (int j = 0; j < 16; j++) most = cnt[j] > most ? cnt[j] : most;
+  for (int step = 0; step < most; step++) {
+    const __m512i st = _mm512_set1_epi64(step);
+    const __mmask8 m0 = _mm512_cmpgt_epi64_mask(c0, st), m1 = _mm512_cmpgt_epi64_mask(c1, st);
+    s0 = _mm512_mask_add_pd(s0, m0, s0, ws), s1 = _mm512_mask_add_pd(s1, m1, s1, ws);
+    n0 = _mm512_mask_add_pd(n0, m0, n0, wn), n1 = _mm512_mask_add_pd(n1, m1, n1, wn);
+  }
+  _mm512_storeu_pd(sh + b_lo, s0), _mm512_storeu_pd(sh + b_lo + 8, s1);
+  _mm512_storeu_pd(ns + b_lo, n0), _mm512_storeu_pd(ns + b_lo + 8, n1);
+}
+
+BinSnpFn pick_bin_snp() {
+  if (std::getenv("COLATE_NO_SIMD")) return nullptr;
+  __builtin_cpu_init();
+  if (__builtin_cpu_supports("avx512f")) return bin_snp_avx512;
+  if (__builtin_cpu_supports("avx2")) return bin_snp_avx2;
+  return nullptr;
+}
+AddSnpFn pick_add_snp() {
+  if (std::getenv("COLATE_NO_SIMD")) return nullptr;
+  __builtin_cpu_init();
+  return __builtin_cpu_supports("avx512f") ? add_snp_avx512 : nullptr;
+}
+
 // ------------------------------------------------------------------ one pair's tables and its walk through the SNPs
 struct UsedSnp {
   double age_begin, age_end, w_sh, w_ns;
@@ -516,6 +606,8 @@ struct Engine {
   SharedUniforms& stream;
   const FastBin& fastbin;
   Pool& pool;
+  BinSnpFn bin_snp = nullptr;  // the vector form of the 100 bins of a SNP where the CPU has one (and the table passed its self-check)
+  AddSnpFn add_snp = nullptr;  // ... and of the additions
 
   // the 100 draws of every SNP of one genome-block segment, in order (coal.cpp:2260-2273, 2279-2295)
   void sample(PairFill& pf, Block& b, const std::vector<UsedSnp>& snps, uint64_t off) const {
@@ -526,12 +618,47 @@ struct Engine {
     double* sh = b.t.data();
     double* ns = sh + A;
     const double age = 0;  // forced, coal.cpp:2074-2075
-    double tmp[100];
+    double tmp[104];
+    const double* const g_lo = fastbin.guard_lo();
+    const double* const g_hi = fastbin.guard_hi();
     for (const UsedSnp& s : snps) {
       if (pf.redo.load(std::memory_order_relaxed)) return;
       const double* u = stream.get100(off, tmp);
+      const bool last_of_chunk = (off % SharedUniforms::kChunk) + 104 > SharedUniforms::kChunk;  // (the vector code reads 104 values)
       off += 100;
       const double span = s.age_end - s.age_begin;
+      if (bin_snp && !s.emp) {
+        // the bins the samples can fall into: from that of age_begin to that of the largest possible sample (u < 1)
+        const int b_lo = fastbin(s.age_begin), b_hi = fastbin(std::nextafter(span + s.age_begin, std::numeric_limits<double>::infinity()));
+        const int K = b_hi + 1 - b_lo;
+        if (b_lo >= 1 && K >= 1 && K <= 16 && b_hi + 1 < A) {
+          if (last_of_chunk && u != tmp) {  // (never read past the chunk: copy the hundred, pad)
+            std::memcpy(tmp, u, 100 * sizeof(double));
+            u = tmp;
+          }
+          if (u == tmp) tmp[100] = tmp[101] = tmp[102] = tmp[103] = 0.0;
+          int bins[104];
+          if (bin_snp(u, span, s.age_begin, g_lo, g_hi, b_lo, K, bins)) {
+            // per bin: as many additions of the SNP's weight as samples fell into it, one after the other -- the same sums as the
+            // sample-by-sample loop below (additions to different bins commute; those to one bin are all of the same addend)
+            int cnt[18] = {0};
+            for (int k = 0; k < 100; k++) cnt[bins[k] - b_lo]++;
+            if (add_snp && K < 16 && b_lo + 16 <= A) {
+              add_snp(sh, ns, b_lo, cnt, s.w_sh, s.w_ns);
+              continue;
+            }
+            for (int j = 0; j <= K; j++) {
+              double a = sh[b_lo + j], r = ns[b_lo + j];
+              for (int n = cnt[j]; n > 0; n--) {
+                a += s.w_sh;
+                r += s.w_ns;
+              }
+              sh[b_lo + j] = a, ns[b_lo + j] = r;
+            }
+            continue;
+          }
+        }
+      }
       if (s.emp) {
         for (int k = 0; k < 100; k++) {
           double sampled_age = u[k] * span + s.age_begin;
@@ -785,7 +912,7 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
   SharedUniforms stream((unsigned)seed, (size_t)(2 * W + 2));
   FastBin fastbin(A, C);
   if (!fastbin.ok()) std::cerr << "Note: the age-bin table failed its self-check; sampling through log()." << std::endl;
-  Engine eng{names, rows, A, C, num_bases_per_block, stream, fastbin, pool};
+  Engine eng{names, rows, A, C, num_bases_per_block, stream, fastbin, pool, fastbin.ok() ? pick_bin_snp() : nullptr, fastbin.ok() ? pick_add_snp() : nullptr};
   std::vector<std::unique_ptr<PairFill>> fills;
   for (size_t p : todo) {
     fills.emplace_back(new PairFill);

@@ -38,6 +38,13 @@ def main(src, dst):
     return out
 
 
+def _kernel_source_sha16():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    return bench.kernel_source_sha16()
+
+
 def pmc_entry(src, fetch_factor, note):
     """One entry of profiles/pmc.json (what bench.py puts into `roofline.traffic` / `roofline.latency.pmc`) from a
     profile directory that has the three PMC passes.  fetch_factor = bytes per FETCH_SIZE-KB/1024 measured by
@@ -54,8 +61,15 @@ def pmc_entry(src, fetch_factor, note):
     cfg = bench["config"]
     iters = cfg["em_iterations_mean"] + 1
     waves = m["SQ_WAVES"]
+    workload = {"replicates": cfg["replicates_rank0"], "epochs": cfg["epochs"], "age_bins": cfg["age_bins"]}
+    if "pairs" in cfg:  # (bench.py --pairs: the EM launch has pairs x replicates rows with per-row epochs)
+        workload = {"pairs": cfg["pairs"], "replicates_per_pair": cfg["replicates_per_pair"], "rows": cfg["replicates_rank0"],
+                    "epochs": cfg["epochs"], "age_bins": cfg["age_bins"]}
     return {
-        "workload": {"replicates": cfg["replicates_rank0"], "epochs": cfg["epochs"], "age_bins": cfg["age_bins"]},
+        "workload": workload,
+        # the kernel sources the counters were taken on (bench.py prices the VALU line with this record only while they are the tree's)
+        # (recomputed from the tree at collection time: tools/collect_profiles.sh runs on the sources the profile was taken on)
+        "kernel_source_sha16": _kernel_source_sha16(),
         "kernel": bench["roofline"]["kernel"], "source": note,
         "hbm_bytes_per_launch": m["FETCH_SIZE"] * 1024 * fetch_factor + m["WRITE_SIZE"] * 1024,
         "fetch_size_kb": m["FETCH_SIZE"], "write_size_kb": m["WRITE_SIZE"], "fetch_factor_8B_per_lane": fetch_factor,

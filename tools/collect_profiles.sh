@@ -4,31 +4,31 @@
 # roofline.traffic / roofline.latency.pmc); the FETCH_SIZE calibration; the bootstrap kernel; the parity sweep.
 set -euo pipefail
 cd "$(dirname "$0")/.."
-src=gpurun_out/prof_r03
-for d in b100_e23 b100_e122 b400_e23 b1024_e23 b4096_e23 b100_e202; do
-  mkdir -p profiles/r03/$d
-  cp $src/$d/summary.txt $src/$d/bench.json profiles/r03/$d/
-  cp $src/$d/kt/runc_kernel_stats.csv profiles/r03/$d/kernel_stats.csv
+src=gpurun_out/prof_r04
+for d in b100_e23 b100_e122 b1000_e23 pairs100x20_e23 b400_e23 b4096_e23; do
+  mkdir -p profiles/r04/$d
+  cp $src/$d/summary.txt $src/$d/bench.json profiles/r04/$d/
+  cp $src/$d/kt/runc_kernel_stats.csv profiles/r04/$d/kernel_stats.csv
 done
-mkdir -p profiles/r03/bootstrap profiles/r03/fetch_calib profiles/parity
-cp $src/bootstrap.json profiles/r03/bootstrap/bench.json
-cp $src/bootstrap/runc_kernel_stats.csv profiles/r03/bootstrap/kernel_stats.csv
-cp $src/calib/runc_counter_collection.csv profiles/r03/fetch_calib/counter_collection.csv
+mkdir -p profiles/r04/bootstrap profiles/r04/fetch_calib profiles/parity
+cp $src/bootstrap.json profiles/r04/bootstrap/bench.json
+cp $src/bootstrap/runc_kernel_stats.csv profiles/r04/bootstrap/kernel_stats.csv
+cp $src/calib/runc_counter_collection.csv profiles/r04/fetch_calib/counter_collection.csv
 factor=$(python3 - <<'PY'
 import csv
-rows = list(csv.DictReader(open("gpurun_out/prof_r03/calib/runc_counter_collection.csv")))
+rows = list(csv.DictReader(open("gpurun_out/prof_r04/calib/runc_counter_collection.csv")))
 fs = [float(r["Counter_Value"]) for r in rows if "read8" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"][0]
 print(805306368 / (fs * 1024))
 PY
 )
-echo "fetch_calib: 805306368 bytes streamed at 8 B per lane; bytes / (FETCH_SIZE x 1024) = $factor" > profiles/r03/fetch_calib/result.txt
+echo "fetch_calib: 805306368 bytes streamed at 8 B per lane; bytes / (FETCH_SIZE x 1024) = $factor" > profiles/r04/fetch_calib/result.txt
 python3 - "$factor" <<'PY'
 import json, subprocess, sys
 factor = float(sys.argv[1])
 entries = []
-for d in ("b100_e23", "b100_e122", "b4096_e23"):
-    out = subprocess.check_output([sys.executable, "profiles/summarize.py", "--pmc-entry", f"gpurun_out/prof_r03/{d}", str(factor),
-                                   f"profiles/r03/{d}/summary.txt (rocprofv3 --pmc, three separate passes over bench.py --steps 3 --warmup 1)"], text=True)
+for d in ("b100_e23", "b100_e122", "b1000_e23", "pairs100x20_e23"):
+    out = subprocess.check_output([sys.executable, "profiles/summarize.py", "--pmc-entry", f"gpurun_out/prof_r04/{d}", str(factor),
+                                   f"profiles/r04/{d}/summary.txt (rocprofv3 --pmc, three separate passes over bench.py --steps 3 --warmup 1)"], text=True)
     entries.append(json.loads(out))
 json.dump(entries, open("profiles/pmc.json", "w"), indent=1)
 print("profiles/pmc.json:", [(e["workload"], round(e["hbm_bytes_per_launch"]), round(e["valu_active_frac_of_wave_cycles"], 3)) for e in entries])

@@ -10,7 +10,7 @@ out=$R/gpurun_out/$name
 mkdir -p "$out"
 cd /tmp
 export TMPDIR=/tmp
-B="$R/bench.py --no-cpu-baseline --no-host-path --no-cxx-rccl-check $*"
+B="$R/bench.py --no-cpu-baseline --no-host-path --no-cxx-rccl-check --no-other-configs $*"
 rocprofv3 --kernel-trace --stats -f csv -d "$out/kt" -o runc -- python3 $B > "$out/bench.json" 2> "$out/kt.log"
 if [ "$pmc" = pmc ]; then
   rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY \
