@@ -60,16 +60,17 @@ struct WorkSeconds {
 };
 WorkSeconds g_work;
 
-// Workers of the pool: COLATE_THREADS, else the hardware threads -- but no more than twice the CPU quota of the control group
-// where there is one (a container with cpu.max = 16 CPUs on a 256-thread host: 256 workers fight over 16 CPUs' worth of
-// time slices, 21-26 s for BASELINE configs[4]; 32 workers: 17 s, profiles/r04/bench/pairs100.txt).
+// Workers of the pool: COLATE_THREADS, else the hardware threads -- but no more than the CPU quota of the control group where
+// there is one (a container with cpu.max = 16 CPUs on a 256-thread host: 256 workers fight over 16 CPUs' worth of time slices,
+// 21-26 s for BASELINE configs[4] against 17 s with 32, profiles/r04/bench/pairs100.txt; with the vectorised sampling the run is
+// CPU-bound at the quota and 16 workers, 11.6 s, beat 32, 12.8 s: pairs100_final.txt).
 int pairs_threads() {
   int n = (int)std::thread::hardware_concurrency();
   if (const char* e = std::getenv("COLATE_THREADS")) return std::max(1, std::min(std::atoi(e), 1024));
   if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
     long long quota = 0, period = 0;
     if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)  // ("max 100000": no quota, fscanf fails)
-      n = (int)std::min<long long>(n, std::max<long long>(2, 2 * ((quota + period - 1) / period)));
+      n = (int)std::min<long long>(n, std::max<long long>(2, (quota + period - 1) / period));
     std::fclose(f);
   }
   return std::max(1, std::min(n, 256));

@@ -191,3 +191,15 @@ def check_rates(r_gpu, flags, r0, mask, rtol=1e-6):
         assert rel[b, :keep].max(initial=0.0) < rtol, ("an epoch the kernel calls resolved differs", b, int(unres[b]),
                                                        int(np.argmax(rel[b, :keep] >= rtol)), float(rel[b, :keep].max()))
     return unres, E - mask.sum(axis=1)
+
+
+def observed_spread_e122():
+    """What the REFERENCE's own real builds print for the 64-replicate whole-genome table at 122 epochs (tests/golden/
+    ref_spread_e122.json, tools/ref_self_reproducibility.py: the stock flags and five alternative flag sets, three of them with
+    FMA contraction): returns (table spec, first epoch kept, {build: rates[64][E - first]} as printed, iterations of the stock build).
+    The observed counterpart of rerun_rates(): where real builds exist, the envelope is theirs."""
+    import json
+
+    fix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_spread_e122.json")))
+    rates = {b: np.array([[float(x) for x in row] for row in v]) for b, v in fix["rates_from_first_epoch"].items()}
+    return fix, fix["first_epoch"], rates, fix["iterations"]["base"]

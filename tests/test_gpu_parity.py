@@ -151,8 +151,10 @@ def test_sparse_tables_and_the_integ_residue(ca):
     """Low-coverage-like tables (a few mutations per age bin): irregular convergence, single epochs with very
     high rates, and behind them epochs whose survival probability is below the resolution of the reference's
     `integ = 1 - num[0] - ...`: there the reference's denominator is the rounding residue of that subtraction and
-    its rate drops to the floor.  The kernel reproduces the residue explicitly (em_kernels.hip, kIntegResidue):
-    same iteration counts, rates within 1e-6 on every resolved epoch, the floor where the reference has it."""
+    its rate drops to the floor.  The kernel models what that residue is made of -- for the not-shared kind the expectation
+    s_b H((x_be - D_b) / s_b) of the frozen rounding error per (bin, epoch), for the shared kind a mean per unit count in the
+    epochs a bin's chain reaches (em_kernel_impl.hpp, `tail model`) --: same iteration counts, rates within
+    1e-6 on every resolved epoch, the floor where the reference has it."""
     from colate_amd import workloads
 
     grid = ol.age_grid()
@@ -252,3 +254,36 @@ def test_more_than_256_epochs(ca, bins, E_expect):
         # unit count, which the kernel models -- DESIGN.md section 6 -- instead of reproducing bit for bit)
         okd = ok & (D0 > 1e-6 * D0.max())
         assert _rel(N1[b][ok], N0[ok]).max() < 1e-9 and _rel(D1[b][okd], D0[okd]).max() < 1e-7 and okd.sum() > 0.8 * ep.size
+
+
+def test_tail_at_122_epochs_lies_inside_the_range_of_the_references_real_builds(ca):
+    """Where the reference stops reproducing ITSELF (tools/ref_self_reproducibility.py: six real builds of its unmodified sources
+    print identical tokens up to epoch 105 of 122 and differ by 15 % at epoch 109, by orders of magnitude beyond) the kernel must
+    print what those builds could print: token-identical to the stock build up to epoch 105, within three of the builds' own
+    spreads at 107 and 108, and at 109 -- the epoch in which the rate falls from 5e-5 towards the floor; round 3 printed 6e-6
+    there, outside every build -- inside the range the builds span over the 64 replicates, as at 110 and 111."""
+    from colate_amd import workloads
+
+    fix, f0, built, it_stock = ol.observed_spread_e122()
+    t = fix["table"]
+    grid = ol.age_grid()
+    ep, _ = ol.epochs_from_bins(fix["bins"])
+    csh, cns = workloads.bootstrap_tables(grid, t["replicates"], nb=t["nb"], scale=t["scale"], ne2=t["ne2"], seed=t["seed"])
+    r1, it1, ll1, fl1 = ca.em_batch(grid, csh, cns, ep)
+    assert it1.tolist() == it_stock and (ca.status_flags(fl1) == 0).all()
+    gpu = np.array([[float("%g" % x) for x in row[f0:]] for row in r1])  # as printed, like the builds
+    stock, others = built["base"], [v for k, v in built.items() if k != "base"]
+    lo = np.minimum.reduce([stock] + others)
+    hi = np.maximum.reduce([stock] + others)
+    spread = np.max([np.abs(o - stock) for o in others], axis=0) / stock
+    for e in range(f0, 106):  # every build prints the same token: so does the kernel
+        assert (gpu[:, e - f0] == stock[:, e - f0]).all(), e
+    for e in (107, 108):
+        rel = np.abs(gpu[:, e - f0] - stock[:, e - f0]) / stock[:, e - f0]
+        assert np.median(rel) <= 3.0 * np.median(spread[:, e - f0]), (e, np.median(rel), np.median(spread[:, e - f0]))
+    for e in (109, 110, 111):  # inside what the builds span over the replicates of this table
+        g = gpu[:, e - f0]
+        assert g.min() >= lo[:, e - f0].min() and g.max() <= hi[:, e - f0].max(), (e, g.min(), g.max(), lo[:, e - f0].min(), hi[:, e - f0].max())
+    rel109 = np.abs(gpu[:, 109 - f0] - stock[:, 109 - f0]) / stock[:, 109 - f0]
+    assert np.median(rel109) <= 3.0 * np.median(spread[:, 109 - f0]), (np.median(rel109), np.median(spread[:, 109 - f0]))
+    assert (ca.unresolved_epochs(fl1) >= 122 - 106).all()  # ... and the kernel says so: everything from 106 on is flagged
