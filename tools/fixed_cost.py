@@ -54,3 +54,21 @@ for bins in ("3,7,0.2", "2,7.95,0.05"):
         print("  max_iter %4d: %8.1f us%s" % (mi, t, extra))
         prev = (mi, t)
     print("  fixed cost (max_iter 1001 minus 1001 steady-state iterations): %.1f us" % (res[-1][1] - 1001 * slope))
+    # the iterations from min_iter on (log-likelihood and stop test in every one): min_iter = 0 and a relative
+    # tolerance of 0 -- ll_i / ll_{i-1} > 1 never holds for an ascending negative log-likelihood --, slope between 140 and 250
+    res_ll = []
+    for mi in (140, 250, 1001):
+        ts = []
+        with torch.cuda.stream(st):
+            for rep in range(12):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                colate_amd.em_batch_device(g, s, n, eps, init, out, it, ll, fl, max_iter=mi, min_iter=0, rel_tol=0.0, stream=st)
+                e1.record(st)
+                st.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+        res_ll.append((mi, float(np.median(ts[3:]))))
+    assert int(it.min()) == 1001, "the stop test fired"
+    d = dict(res_ll)
+    print("  log-likelihood phase (min_iter = 0, rel_tol = 0): %.4f us per iteration; max_iter 1001: %.1f us (without: %.1f)"
+          % ((d[250] - d[140]) / 110.0, d[1001], dict(res)[1001]))
