@@ -272,7 +272,11 @@ constexpr int em_loop_pad(int mode, int nch, int erows, bool tput, int wpe) {
   // E=23 B=100 (the build without the register cap, two barriers) 0.895 0.897 0.903 0.906 0.910 0.887 0.901 0.916;
   // E=122 B=100 1.308 1.309 1.308 1.314 1.316 1.317 1.335 1.338 (with the tail model's per-iteration load still in the loop);
   // E=23 B=400 (with the cap) 1.144 1.146 1.149 1.138 1.145 1.154 1.134 1.148
-  return nch == 1 ? (wpe == 2 ? 5 : 6) : 0;
+  // ... and again at the end of round 4 (refresh block and prologue trimmed; gpurun_out/t2/padsweep.txt -> profiles/r04_placement_raw.txt):
+  // E=23 B=100 0.896 0.899 0.910 0.914 0.916 0.890 0.906 0.922 (the build before: 0.893, round 3's: 0.881);
+  // E=122 B=100 1.256 1.258 1.249 1.254 1.252 1.263 1.267 1.275 (the build before: 1.310, round 3's: 1.224);
+  // E=23 B=400 1.149 1.156 1.155 1.142 1.147 1.156 1.139 1.150 (1.146, 1.140)
+  return nch == 1 ? (wpe == 2 ? 5 : 6) : 2;
 #else
   (void)nch;
   if (!tput) return 6;  // latency variant, default build (not picked by colate_em_variant any more; COLATE_EM_VARIANT=latency)
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     // The bins of epoch e are [lo, hi) -- the ages ascend, so the bins' epochs do --: two bisections of s_kb instead of a walk over
     // all bins per lane, which was 22 (42) us per launch at 23 (122) epochs.  An epoch without bins: lo == hi, no tail slots.
     int lo = A, hi = 0, n_before = 0;
-    double c_later = 0.0, c_ge = 0.0;
+    double c_later = 0.0;
     if (ep_on[c]) {
       lo = hi = 0;
       for (int len = A; len > 0;) {  // first b with s_kb[b] >= e
@@ -572,9 +576,7 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
     }
     {  // counts of the later bins, b >= hi, summed in ascending order as before (a bin outside the data has a count of 0, and
        // x + 0.0 == x): one walk over the bins with data for the whole wave, every lane adding from its own hi on
-      // (c_ge: the counts of the epoch's own bins and the later ones, b >= lo -- the bins whose own integ chain reaches this
-      // epoch, coal_EM.cpp:266-278 --; the walk starts at the slot's smallest lo, and the extra zeros leave c_later's bits alone)
-      int b0 = __builtin_amdgcn_readfirstlane(lo);  // (lane 0 holds the slot's earliest epoch: the smallest lo and hi)
+      int b0 = __builtin_amdgcn_readfirstlane(hi);  // (lane 0 holds the slot's earliest epoch: the smallest hi)
       if (b0 < nzlo) b0 = nzlo;
       for (int b = b0; b < nzhi; b += 8) {  // (eight loads in flight; the row is zero from nzhi up to AP)
         double v[8];
@@ -583,19 +585,12 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           // (b + j < nzhi: the last round of eight may reach past the row's zero padding -- up to AP + 1 -- into what lies behind
-          // it in LDS, e.g. another launch's log-likelihood partials: round 4's fuzz, 46 cases, once the walk started at lo)
+          // it in LDS, e.g. another launch's log-likelihood partials: round 4's fuzz, 46 cases, when the walk started elsewhere)
           c_later += (ep_on[c] && b + j >= hi && b + j < nzhi) ? v[j] : 0.0;
-          c_ge += (ep_on[c] && b + j >= lo && b + j < nzhi) ? v[j] : 0.0;
         }
       }
     }
     C0[c] = c_later;
-    // role A: dt_e * mean residue of the shared bins WHOSE CHAIN REACHES EPOCH e (0 in the last epoch, which has no dt_e * integ
-    // term).  A shared bin's integ recurrence stops at the bin's own epoch (coal_EM.cpp:266-278: e = 0 .. min(E - 2, k)); behind
-    // it the bin adds nothing to any denominator -- round 3 charged every epoch with the residue of ALL shared counts, which in
-    // the flat epochs behind all data pulled the rate down ten times faster than any real build of the reference does
-    // (profiles/parity/ref_self_reproducibility_e122.json: epoch 109 of --bins 2,7.95,0.05).
-    if (role == 0) eta_e[c] = dt_e[c] * (kIntegResidue * c_ge);
     nlt[c] = n_before;
     const int clo = (lo > nzlo ? lo : nzlo) - nzlo, chi = (hi < nzhi ? hi : nzhi) - nzlo;  // compacted, clipped
     seg_hi[c] = chi;
@@ -609,6 +604,21 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
       if (r1 > r0 + 1) slot2[c] = ((r0 + 2) * 16 + 15 < chi - 1) ? (r0 + 2) * 16 + 15 : chi - 1;
       row_x[c] = r0 + 3;  // rows beyond the first three (rare: an epoch spanning > 48 bins with data)
       row_hi[c] = r1;
+    }
+  }
+  // role A: dt_e * mean residue of the shared bins WHOSE CHAIN REACHES EPOCH e (0 in the last epoch, which has no dt_e * integ
+  // term).  A shared bin's integ recurrence stops at the bin's own epoch (coal_EM.cpp:266-278: e = 0 .. min(E - 2, k)); behind
+  // it the bin adds nothing to any denominator -- round 3 charged every epoch with the residue of ALL shared counts, which in
+  // the flat epochs behind all data pulled the rate down ten times faster than any real build of the reference does
+  // (profiles/parity/ref_self_reproducibility_e122.json: epoch 109 of --bins 2,7.95,0.05).  The counts of the epoch's own bins
+  // and the later ones, b >= lo(e), are the previous epoch's c_later -- lo(e) = hi(e - 1): the same terms in the same order --,
+  // one lane (or slot) over; epoch 0: all counts.
+  if (role == 0) {
+    const double from_below = dpp_d<WAVE_SHR1, 0xf, true>(0.0, C0[NCH - 1]);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      const double c_ge = (c == 0) ? (lane == 0 ? c_all : from_below) : C0[c - 1];
+      eta_e[c] = dt_e[c] * (kIntegResidue * c_ge);
     }
   }
   bool more_rows[NCH];  // (wave-uniform) some epoch of the slot spans more than three 16-lane rows
@@ -742,16 +752,26 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
   if (kFree) last_pos = (ballot64(lam_e[0] > 0.0) & last_bit1) != 0ull;
   if (TPUT) last_pos = last_rate_positive();
   // (the tail model's refresh schedule -- see `tail model` in P3.  More than 64 epochs: the powers of two up to 128 and then
-  // every 128th iteration.  Up to 64: the powers of two, and every 32nd iteration while the last refresh found an epoch in
+  // every 128th iteration -- fifteen refreshes in 1001 iterations.  Tried at the end of round 4: every 256th from 256 on (twelve)
+  // saves 16 us per launch and puts epoch 111 of --bins 2,7.95,0.05 at 8.5e-7, outside the range of the reference's real builds
+  // (<= 1.6e-7; tests/test_gpu_parity.py::test_tail_at_122_epochs_...): the study tool's "up to 256" did not survive the GPU.  Up to 64: the powers of two, and every 32nd iteration while the last refresh found an epoch in
   // transition; the flag only changes inside a refresh, so due / next-due stay consistent along a run.)
   auto tail_due = [&](int it) {
+#ifdef COLATE_TAIL_LATE256  // (A/B switch: every 256th from 512 on)
+    if (NCH >= 2) return it < 128 ? (it & (it - 1)) == 0 : (it < 512 ? (it & 127) == 0 : (it & 255) == 0);
+#else
     if (NCH >= 2) return it < 128 ? (it & (it - 1)) == 0 : (it & 127) == 0;
+#endif
     return (it & (it - 1)) == 0 || (!tail_trivial_prev && (it & 31) == 0);
   };
   auto tail_next_due = [&](int it) {  // first due iteration >= it
     if (it <= 1) return it;
     const int p2 = 1 << (32 - __builtin_clz((unsigned)(it - 1)));
+#ifdef COLATE_TAIL_LATE256
+    if (NCH >= 2) return it <= 128 ? p2 : (it <= 512 ? ((it + 127) & ~127) : ((it + 255) & ~255));
+#else
     if (NCH >= 2) return it <= 128 ? p2 : ((it + 127) & ~127);
+#endif
     const int m32 = (it + 31) & ~31;
     return (!tail_trivial_prev && m32 < p2) ? m32 : p2;
   };
@@ -1343,15 +1363,18 @@ __global__ __launch_bounds__(TPUT ? 2 * kWave : 2 * COLATE_EM_MAX_A, WPE ? WPE :
                 const double mb = em::em_exp_t(__builtin_fmin(csa, 230.0), s_exptab);  // 1 / S(age), capped at 1e100
                 double Db = 0.0;
                 int ndrop = 0;
-                for (int e = e_sm; e < E; e++) {  // (uniform; W_e from the epoch lanes of this wave)
-                  double w_s = 0.0;
+                // (uniform; W_e from the epoch lanes of this wave, a lane's NCH epochs per round: the slot as a run-time index was
+                // two branches per epoch -- 25 instructions and ~140 cycles each; an epoch in front of e_sm has no bin that
+                // drops its term, and one beyond E a term of 0 that the bound keeps out)
+                for (int eb = e_sm & ~(NCH - 1); eb < E; eb += NCH) {
 #pragma unroll
-                  for (int c = 0; c < NCH; c++)
-                    if (NCH == 1 || (e & (NCH - 1)) == c) w_s = readlane_d(We[c], e >> kSlotShift);
-                  const double w = w_s * mb;
-                  const bool dr = (e > kq) && (w < th);
-                  Db += dr ? w : 0.0;
-                  ndrop += dr ? 1 : 0;
+                  for (int c = 0; c < NCH; c++) {
+                    const int e = eb + c;
+                    const double w = readlane_d(We[c], eb >> kSlotShift) * mb;
+                    const bool dr = (e < E) && (e > kq) && (w < th);
+                    Db += dr ? w : 0.0;
+                    ndrop += dr ? 1 : 0;
+                  }
                 }
                 const int nfold = E - 1 - kq - ndrop;
                 const double xk = lkb * (tknb - tkb);
