@@ -14,6 +14,8 @@
 //   * the pairs advance through that stream window by window, so the ring stays bounded (COLATE_UNIFORM_WINDOW_MB) however
 //     long the stream a pair needs; inside a window every pair's SNP walk is a task and every (pair, genome block) a
 //     sampling job on one pool of COLATE_THREADS workers: the pairs fill in parallel, and so do the blocks of one pair;
+//   * where there is a GPU the sampling jobs run THERE (fill_device.h: the uniform stream uploaded once, a wave per (pair, block),
+//     same arithmetic, same tables bit for bit; COLATE_DEVICE_FILL=0 keeps them on the host): the workers then only walk;
 //   * the block bootstrap of all pairs runs on the GPU in one launch (bootstrap_groups_kernel) in front of ONE EM launch per
 //     distinct number of epochs (per-row epochs: an ancient sample inserts its age as an epoch, coal.cpp:3597-3624);
 //   * `--ranks N`: the rows (pair, replicate) are sharded over N processes, one per GPU; a rank fills only the pairs its
@@ -43,6 +45,7 @@
 
 #include "colate_amd.h"
 #include "colate_internal.h"
+#include "fill_device.h"
 #include "mut_feeder.h"
 
 namespace colate_drv {
@@ -329,6 +332,11 @@ class SharedUniforms {
     return tmp;
   }
   double get1(uint64_t off) { return slot(off / kChunk).u[off % kChunk]; }
+  const double* chunk(uint64_t c) { return slot(c).u.data(); }  // (waits until it has been generated)
+  template <typename F>
+  void for_each_buffer(F f) {  // (the ring's memory, e.g. to page-lock it for uploads)
+    for (Slot& s : ring_) f(s.u.data(), s.u.size() * sizeof(double));
+  }
   // the generator as a sequential run holds it after `off` uniforms
   bool state_at(uint64_t off, std::mt19937& g) {
     BulkMt19937 b = slot(off / kChunk).at_start;
@@ -589,6 +597,10 @@ struct PairFill {
   uint64_t off = 0;  // uniforms taken so far
   std::vector<UsedSnp> pending;
   uint64_t pending_off = 0;
+  // sampling on the device: the records of the block being walked (handed over when the block is complete) and this pair's tables there
+  std::vector<FillRec> dev_cur;
+  uint64_t dev_cur_off = 0;
+  size_t slot = 0;
   bool walked = false;
   double inline_sample_s = 0;  // seconds this pair's walker spent sampling itself (pool full)
   // results
@@ -596,6 +608,17 @@ struct PairFill {
   std::atomic<bool> redo{false};  // a sample beyond the age grid had to be redrawn: this pair is filled sequentially afterwards
   std::mt19937 rng_end;
   size_t used_snps = 0;
+};
+
+// (pair, block) jobs whose block is complete, waiting for the next hand-over to the device (fill_pairs, at the end of a window)
+struct DevQueue {
+  static constexpr uint32_t kMaxBlocks = 512;  // tables per pair on the device (a pair with more goes back to the host)
+  std::mutex m;
+  struct Item {
+    FillJob job;
+    std::vector<FillRec> recs;
+  };
+  std::vector<Item> ready;
 };
 
 struct Engine {
@@ -609,6 +632,7 @@ struct Engine {
   Pool& pool;
   BinSnpFn bin_snp = nullptr;  // the vector form of the 100 bins of a SNP where the CPU has one (and the table passed its self-check)
   AddSnpFn add_snp = nullptr;  // ... and of the additions
+  DevQueue* devq = nullptr;    // not null: the sampling runs on the device (fill_device.h)
 
   // the 100 draws of every SNP of one genome-block segment, in order (coal.cpp:2260-2273, 2279-2295)
   void sample(PairFill& pf, Block& b, const std::vector<UsedSnp>& snps, uint64_t off) const {
@@ -683,6 +707,7 @@ struct Engine {
   }
 
   void flush(PairFill& pf) const {  // hand the current block's pending SNPs to the pool (or run them here when it is full)
+    if (devq) return;  // (on the device a block is one job: its records wait in dev_cur until advance_block)
     if (pf.pending.empty()) return;
     auto snps = std::make_shared<std::vector<UsedSnp>>(std::move(pf.pending));
     pf.pending = std::vector<UsedSnp>();
@@ -698,6 +723,20 @@ struct Engine {
   }
   void advance_block(PairFill& pf) const {
     flush(pf);
+    if (devq && !pf.dev_cur.empty()) {
+      const size_t had = pf.dev_cur.size();
+      if (pf.blk >= DevQueue::kMaxBlocks || pf.dev_cur.size() > 0xffffffffull) {
+        pf.redo.store(true);
+      } else {
+        DevQueue::Item it;
+        it.job = FillJob{0, pf.dev_cur_off, (uint32_t)pf.dev_cur.size(), (uint32_t)(pf.slot * DevQueue::kMaxBlocks + pf.blk)};
+        it.recs = std::move(pf.dev_cur);
+        std::lock_guard<std::mutex> lk(devq->m);
+        devq->ready.push_back(std::move(it));
+      }
+      pf.dev_cur = std::vector<FillRec>();
+      pf.dev_cur.reserve(had + had / 8);  // (the next block is about as long: no doubling copies on the way)
+    }
     pf.blk++;
     pf.num_blocks++;
     if (pf.blk >= pf.blocks.size()) pf.blocks.emplace_back(new Block(A));
@@ -775,6 +814,7 @@ struct Engine {
         f_AAF_target = std::round(f_AAF_target);
         const int DAF_ref = ref.DAF;
         if (pf.pending.empty()) pf.pending_off = pf.off;
+        if (devq && pf.dev_cur.empty()) pf.dev_cur_off = pf.off;
         if (age_begin <= age) {  // coal.cpp:2245-2275
           const int bin2 = age_bin_index(m.age_end, C);
           if (bin2 < A) {  // row 0 of the A*A table; larger indices land in rows nobody reads
@@ -782,10 +822,13 @@ struct Engine {
             t[2 * A + bin2] += f_DAF_target * DAF_ref / ((double)N_ref);
             t[3 * A + bin2] += f_AAF_target * DAF_ref / ((double)N_ref);
           }
-          pf.pending.push_back(UsedSnp{age_begin, (double)m.age_end, 0.0, f_AAF_target * DAF_ref / ((double)N_ref * num_samples), true});
+          const double w_ns = f_AAF_target * DAF_ref / ((double)N_ref * num_samples);
+          if (devq) pf.dev_cur.push_back(FillRec{(float)age_begin, m.age_end, 0.0, w_ns});  // (age_begin: a float, or the sample age 0)
+          else pf.pending.push_back(UsedSnp{age_begin, (double)m.age_end, 0.0, w_ns, true});
         } else {  // coal.cpp:2277-2297
-          pf.pending.push_back(UsedSnp{age_begin, (double)m.age_end, f_DAF_target * DAF_ref / ((double)N_ref * num_samples),
-                                       f_AAF_target * DAF_ref / ((double)N_ref * num_samples), false});
+          const double w_sh = f_DAF_target * DAF_ref / ((double)N_ref * num_samples), w_ns = f_AAF_target * DAF_ref / ((double)N_ref * num_samples);
+          if (devq) pf.dev_cur.push_back(FillRec{(float)age_begin, m.age_end, w_sh, w_ns});
+          else pf.pending.push_back(UsedSnp{age_begin, (double)m.age_end, w_sh, w_ns, false});
         }
         pf.off += 100;
         pf.used_snps++;
@@ -868,6 +911,58 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
     return true;
   }
 
+  // ---- the shared uniform stream (its producer starts now), the age-bin table, and -- where there is a GPU -- the sampling on the
+  // device (fill_device.h).  The host code is what runs otherwise, and for any pair the device hands back.
+  size_t window_mb = 64;
+  if (const char* e = std::getenv("COLATE_UNIFORM_WINDOW_MB")) window_mb = (size_t)std::max(4, std::atoi(e));
+  const uint64_t W = std::max<uint64_t>(2, window_mb * (1u << 20) / (SharedUniforms::kChunk * sizeof(double)));  // chunks per window
+  SharedUniforms stream((unsigned)seed, (size_t)(2 * W + 2));
+  FastBin fastbin(A, C);
+  if (!fastbin.ok()) std::cerr << "Note: the age-bin table failed its self-check; sampling through log()." << std::endl;
+  std::unique_ptr<DeviceFill> dev;
+  DevQueue devq;
+  std::string dev_note;
+  std::thread dev_maker;
+  bool dev_pending = false, dev_staging_ok = false;
+  int dev_device = 0;
+  size_t dev_batch = 0;
+  double dev_make_s = 0, dev_staging_s = 0;
+  {
+    const char* e = std::getenv("COLATE_DEVICE_FILL");
+    const bool want = !(e && std::atoi(e) == 0);
+    if (!want) dev_note = "COLATE_DEVICE_FILL=0";
+    else if (!fastbin.ok()) dev_note = "no age-bin table";
+    else if (!DeviceFill::available()) dev_note = "no HIP device";
+    else {
+      int device = 0;
+      try {
+        if (opt.has("device")) device = std::stoi(opt.get("device"));
+      } catch (...) {
+        device = 0;
+      }
+      if (g_rank.ranked) device += g_rank.rank;
+      // a batch: COLATE_DEVICE_FILL_BATCH records (24 bytes each, two pinned buffers; 64 M by default) -- or all there can be: a pair
+      // uses a row at most once, and a row of a .mut file is more than four bytes even compressed
+      uint64_t rows_bound = 0;
+      for (const std::string& f : mut_files) {
+        struct stat st;
+        if (::stat(f.c_str(), &st) == 0) rows_bound += (uint64_t)st.st_size / 4 + 1;
+        else if (::stat((f + ".gz").c_str(), &st) == 0) rows_bound += (uint64_t)st.st_size / 4 + 1;
+      }
+      size_t batch = (size_t)64 << 20;
+      if (const char* b = std::getenv("COLATE_DEVICE_FILL_BATCH")) batch = (size_t)std::max(1024, std::atoi(b));
+      batch = std::min<uint64_t>(batch, std::max<uint64_t>(1024, rows_bound * todo.size()));
+      dev_pending = true;
+      dev_device = device, dev_batch = batch;
+    }
+  }
+  struct JoinMaker {
+    std::thread& t;
+    ~JoinMaker() {
+      if (t.joinable()) t.join();
+    }
+  } join_maker{dev_maker};
+
   Pool pool(T);
   // ---- every input file once
   std::vector<HugeVector<CompactRow>> rows(mut_files.size());
@@ -907,22 +1002,86 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
   for (auto& kv : tmp_files) n_rec += kv.second->size;
 
   // ---- the pairs, window by window through the shared uniform stream
-  size_t window_mb = 64;
-  if (const char* e = std::getenv("COLATE_UNIFORM_WINDOW_MB")) window_mb = (size_t)std::max(4, std::atoi(e));
-  const uint64_t W = std::max<uint64_t>(2, window_mb * (1u << 20) / (SharedUniforms::kChunk * sizeof(double)));  // chunks per window
-  SharedUniforms stream((unsigned)seed, (size_t)(2 * W + 2));
-  FastBin fastbin(A, C);
-  if (!fastbin.ok()) std::cerr << "Note: the age-bin table failed its self-check; sampling through log()." << std::endl;
-  Engine eng{names, rows, A, C, num_bases_per_block, stream, fastbin, pool, fastbin.ok() ? pick_bin_snp() : nullptr, fastbin.ok() ? pick_add_snp() : nullptr};
+  bool dev_failed = false;
+  if (dev_pending) {
+    const double t0m = now_s();
+    const uint64_t max_uniforms = ((uint64_t)n_kept * 100 / SharedUniforms::kChunk + W + 3) * SharedUniforms::kChunk;  // a pair uses at most every kept row
+    dev.reset(DeviceFill::create(dev_device, A, fastbin.guard_lo(), fastbin.guard_hi(), todo.size() * DevQueue::kMaxBlocks,
+                                 std::min<uint64_t>(dev_batch, std::max<uint64_t>(1024, (uint64_t)n_kept * todo.size())), dev_note));
+    if (!dev || !dev->alloc_uniforms(max_uniforms)) {
+      std::cerr << "Note: age sampling on the GPU could not be set up (" << (dev ? dev->error() : dev_note) << "); sampling on the host." << std::endl;
+      if (dev) dev_note = dev->error();
+      dev.reset();
+      dev_pending = false;
+    } else {
+      stream.for_each_buffer([&](double* p, size_t bytes) { dev->pin(p, bytes); });
+      dev_make_s = now_s() - t0m;
+      // (the record buffers -- gigabytes to page-lock -- beside the first windows: the first hand-over waits for them)
+      dev_maker = std::thread([&] {
+        const double t1m = now_s();
+        dev_staging_ok = dev->alloc_staging();
+        dev_staging_s = now_s() - t1m;
+      });
+    }
+  }
+  Engine eng{names, rows, A, C, num_bases_per_block, stream, fastbin, pool, fastbin.ok() ? pick_bin_snp() : nullptr, fastbin.ok() ? pick_add_snp() : nullptr,
+             dev_pending ? &devq : nullptr};
   std::vector<std::unique_ptr<PairFill>> fills;
   for (size_t p : todo) {
     fills.emplace_back(new PairFill);
     PairFill& pf = *fills.back();
     pf.index = p;
+    pf.slot = fills.size() - 1;
     pf.tgt_file = tmp_files[pairs[p].target].get(), pf.ref_file = tmp_files[pairs[p].reference].get();
     pf.tgt.open(*pf.tgt_file), pf.ref.open(*pf.ref_file);
   }
   int windows = 0;
+  uint64_t dev_next_chunk = 0;
+  size_t dev_jobs = 0, dev_recs = 0, dev_launches = 0;
+  double dev_upload_s = 0, dev_finish_s = 0;
+  // Hand-over to the device.  A job is a chain of dependent additions, SNP after SNP, on one wave: what makes the GPU fast is the
+  // number of chains in flight.  A window completes ~2 blocks per pair -- 180 jobs for 1024 SIMDs, 145 ms per launch however few
+  // they are --, so the completed blocks are kept until half a staging buffer of records has come together (some 2000 jobs at
+  // BASELINE configs[4]) and go in one launch: their records side by side into the pinned buffer (the pool copies).
+  std::vector<DevQueue::Item> backlog;
+  size_t backlog_recs = 0;
+  auto hand_over = [&](bool all) {
+    while (dev && !dev_failed && !backlog.empty() && (all || backlog_recs >= dev->staging_capacity() / 2)) {
+      if (dev_maker.joinable()) {
+        dev_maker.join();
+        if (!dev_staging_ok) {
+          dev_failed = true;
+          break;
+        }
+      }
+      std::vector<FillJob> jobs;
+      size_t nrecs = 0, taken = 0;
+      for (; taken < backlog.size() && jobs.size() < 60000; taken++) {
+        DevQueue::Item& it = backlog[taken];
+        if (it.recs.size() > dev->staging_capacity()) {  // (a block larger than a batch: the host takes the pair)
+          fills[it.job.table / DevQueue::kMaxBlocks]->redo.store(true);
+          backlog_recs -= it.recs.size();
+          it.recs.clear();
+          continue;
+        }
+        if (nrecs + it.recs.size() > dev->staging_capacity()) break;
+        it.job.rec_off = nrecs;
+        nrecs += it.recs.size();
+        if (!it.recs.empty()) jobs.push_back(it.job);
+      }
+      FillRec* const dst = dev->staging();
+      for (size_t i = 0; i < taken; i++)
+        if (!backlog[i].recs.empty()) {
+          DevQueue::Item* itp = &backlog[i];
+          pool.submit([dst, itp] { std::memcpy(dst + itp->job.rec_off, itp->recs.data(), itp->recs.size() * sizeof(FillRec)); });
+        }
+      pool.wait_idle();
+      dev_jobs += jobs.size(), dev_recs += nrecs, dev_launches += jobs.empty() ? 0 : 1;
+      if (!dev->submit(jobs, nrecs)) dev_failed = true;
+      backlog_recs -= nrecs;
+      backlog.erase(backlog.begin(), backlog.begin() + (long)taken);
+    }
+  };
   for (uint64_t w = 0;; w++) {
     const uint64_t limit = (w + 1) * W * SharedUniforms::kChunk;
     bool any = false;
@@ -934,8 +1093,46 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
       }
     if (!any) break;
     pool.wait_idle();
+    if (dev && !dev_failed) {
+      // the uniforms this window's jobs read (a pair's last SNP of the window may reach 100 into the next chunk) ...
+      const double tu = now_s();
+      for (; dev_next_chunk <= (w + 1) * W; dev_next_chunk++)
+        if (!dev->upload_uniforms(dev_next_chunk * SharedUniforms::kChunk, stream.chunk(dev_next_chunk), SharedUniforms::kChunk)) dev_failed = true;
+      dev_upload_s += now_s() - tu;
+      // ... and the blocks that were completed in it join the backlog
+      {
+        std::lock_guard<std::mutex> lk(devq.m);
+        for (DevQueue::Item& it : devq.ready) {
+          backlog_recs += it.recs.size();
+          backlog.push_back(std::move(it));
+        }
+        devq.ready.clear();
+      }
+      hand_over(false);
+    }
     stream.release_before((w + 1) * W);
     windows++;
+  }
+  if (dev) {  // the tables of every (pair, block) back from the device; a pair with a flagged block is filled again on the host
+    const double tf = now_s();
+    hand_over(true);
+    std::vector<double> dtab;
+    std::vector<int> dflags;
+    if (dev_failed || !dev->finish(dtab, dflags)) {
+      std::cerr << "Note: age sampling on the GPU failed (" << dev->error() << "); filling the pairs on the host." << std::endl;
+      for (auto& pf : fills) pf->redo.store(true);
+    } else {
+      for (auto& pfp : fills) {
+        PairFill& pf = *pfp;
+        if (pf.redo.load()) continue;
+        for (int j = 0; j < pf.num_blocks && !pf.redo.load(); j++) {
+          const size_t t = pf.slot * DevQueue::kMaxBlocks + (size_t)j;
+          if (dflags[t]) pf.redo.store(true);
+          else std::copy(dtab.begin() + t * 2 * A, dtab.begin() + (t + 1) * 2 * A, pf.blocks[(size_t)j]->t.begin());
+        }
+      }
+    }
+    dev_finish_s = now_s() - tf;
   }
   const double t2 = now_s();
   size_t redone = 0, used = 0;
@@ -967,7 +1164,12 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
               << " stream window(s) of " << window_mb << " MB, waited " << stream.waited() << " thread-s for uniforms, " << redone
               << " pair(s) redone sequentially in " << now_s() - t2 << " s); thread-seconds: .mut parse " << g_work.parse_mut.load()
               << ", .colate.in decode " << g_work.load_tmp.load() << ", SNP walks " << g_work.walk.load() << ", age sampling "
-              << g_work.sample.load() << std::endl;
+              << g_work.sample.load()
+              << (dev ? "; age sampling on the GPU: " + std::to_string(dev_jobs) + " (pair, block) jobs, " + std::to_string(dev_recs) + " SNPs in " + std::to_string(dev_launches) + " launches, " +
+                            std::to_string(dev->gpu_seconds()) + " s of copies and kernels, " + std::to_string(dev_upload_s) + " s uploading the uniform stream, " + std::to_string(dev_make_s) + " s setting up, " + std::to_string(dev_staging_s) + " s page-locking the record buffers beside the first windows, " +
+                            std::to_string(dev_finish_s) + " s for the last launch and the tables"
+                      : "; age sampling on the host (" + dev_note + ")")
+              << std::endl;
   g_times.parse_mut = t1 - t0;
   g_times.table_fill = now_s() - t1;
   return true;

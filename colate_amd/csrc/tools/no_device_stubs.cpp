@@ -68,3 +68,21 @@ int colate_bootstrap_em_batch_allgather(void*, int, int, int, int, const double*
                                         const double*, const double*, const double*, const double*, const double*, int, int,
                                         double, double, double*, int*, double*, int*) { return nodev(); }
 }
+
+// the age sampling on the device (fill_device.h): there is none in this build, the host code samples
+#include "fill_device.h"
+namespace colate_drv {
+DeviceFill* DeviceFill::create(int, int, const double*, const double*, size_t, size_t, std::string& why) {
+  why = "built without a device";
+  return nullptr;
+}
+bool DeviceFill::available() { return false; }
+DeviceFill::~DeviceFill() {}
+bool DeviceFill::alloc_staging() { return false; }
+bool DeviceFill::alloc_uniforms(uint64_t) { return false; }
+void DeviceFill::pin(void*, size_t) {}
+bool DeviceFill::upload_uniforms(uint64_t, const double*, size_t) { return false; }
+bool DeviceFill::submit(const std::vector<FillJob>&, size_t) { return false; }
+bool DeviceFill::finish(std::vector<double>&, std::vector<int>&) { return false; }
+bool DeviceFill::fail(const char*, int) { return false; }
+}  // namespace colate_drv

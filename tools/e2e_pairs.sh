@@ -23,17 +23,22 @@ echo "host: $(nproc) cores, $(awk '/MemTotal/ {printf "%.0f GB", $2 / 1e6}' /pro
 common="--mode mut --mut P --chr chr.txt --bins 3,7,0.2 --seed 1 --num_bootstraps $B"
 cd "$d"
 
-for threads in ${THREADS:-default 32 default}; do
+# (round 4, last: the age sampling of the table fill runs on the GPU by default -- fill_device.h --; `host` = COLATE_DEVICE_FILL=0.
+#  The last run is the one whose .coal files are compared with the reference's.)
+for run in ${RUNS:-host:default device:32 device:default}; do
+  fill=${run%%:*}; threads=${run##*:}
   t0=$(now)
   if [ "$threads" = default ]; then unset COLATE_THREADS; else export COLATE_THREADS=$threads; fi
+  if [ "$fill" = host ]; then export COLATE_DEVICE_FILL=0; else unset COLATE_DEVICE_FILL; fi
+  case "$fill" in device[0-9]*) export COLATE_UNIFORM_WINDOW_MB=${fill#device};; *) unset COLATE_UNIFORM_WINDOW_MB;; esac  # (deviceNNN: stream windows of NNN MB)
   COLATE_TIMING=1 "$R/colate_amd/bin/Colate" $common --pairs pairs.txt > ours.out 2> ours.err
-  echo "colate_amd --pairs (COLATE_THREADS=$threads): $(since $t0) s wall for $P pairs x $B replicates"
+  echo "colate_amd --pairs (age sampling on the $fill, COLATE_THREADS=$threads): $(since $t0) s wall for $P pairs x $B replicates"
   grep '^Timing' ours.err | sed 's/^/    /'
 done
-unset COLATE_THREADS
+unset COLATE_THREADS COLATE_DEVICE_FILL COLATE_UNIFORM_WINDOW_MB
 grep '^CPU Time' ours.err | sed 's/^/    /'
 
-if [ -x "$R/oracle/_ref/Colate_ref" ]; then
+if [ -x "$R/oracle/_ref/Colate_ref" ] && [ -z "${SKIP_REF:-}" ]; then
   t0=$(now)
   run_ref() {  # one reference run: target reference output
     local s=$(date +%s.%N)
