@@ -198,11 +198,25 @@ bool compact_row(const MutRow& m, CompactRow& c) {
 //   int32 lchrom; char chrom[lchrom]; int32 bp; char anc; char der; int32 AAF; int32 DAF
 // The file is mapped once (one copy in memory, the page cache's, whatever number of pairs walk it) and every pair's cursor
 // decodes records straight out of the mapping.
+// ... and decoded ONCE: the walk of every pair that takes the file then steps through 16-byte records instead of decoding the bytes
+// (a length, a name to copy and compare, five fields) again -- with 10 x 10 pairs every file was decoded ten times, 4.4 G records, most
+// of the 60 thread-seconds the walks of BASELINE configs[4] took.  The records are what the byte cursor below (the reference's fread
+// calls) yields, call by call, so nothing about a short last record or a persisting name buffer changes.
+struct DecRec {
+  int32_t bp, AAF, DAF;
+  uint16_t chrom;  // index into TmpFile::names (0: the empty name the buffer starts with)
+  char anc, der;
+};
+static_assert(sizeof(DecRec) == 16, "DecRec");
+
 struct TmpFile {
   std::string path;
   const char* data = nullptr;
   size_t size = 0;
   bool ok = false;
+  HugeVector<DecRec> recs;
+  std::vector<std::string> names{std::string()};
+  bool decoded = false;  // false: more than 65535 distinct names -- the walks decode the bytes themselves
   TmpFile() = default;
   TmpFile(const TmpFile&) = delete;
   TmpFile& operator=(const TmpFile&) = delete;
@@ -237,13 +251,14 @@ bool load_tmp_file(TmpFile& f) {
 
 // The reference's FILE* together with the variables its fread calls fill (coal.cpp:2085-2087, 2126-2133): a field the file
 // ends in front of (or inside) keeps the bytes it had, exactly as with fread; the name buffer persists from record to record.
-struct Cursor {
+struct ByteCursor {
   const char *p = nullptr, *end = nullptr;
   char chrom[1025] = {0};
   const char* name = "";  // the chromosome the walk is at
   bool match = true;      // strcmp(chrom, name) == 0
   int bp = 0, AAF = 0, DAF = 0;  // AAF, DAF: the walk resets them between SNPs (coal.cpp:2182-2183)
   char anc = 0, der = 0;
+  bool partial = false;
   void open(const TmpFile& f) { p = f.data, end = f.data + f.size; }
   void set_name(const char* n) {
     name = n;
@@ -265,6 +280,7 @@ struct Cursor {
       std::memcpy(&DAF, p + 10, 4);
       p += 14;
     } else {
+      partial = true;  // (the file ends inside this record)
       take(chrom, (size_t)l);
       take(&bp, 4), take(&anc, 1), take(&der, 1), take(&AAF, 4), take(&DAF, 4);
     }
@@ -278,6 +294,79 @@ struct Cursor {
     const size_t k = std::min(n, (size_t)(end - p));
     std::memcpy(dst, p, k);
     p += k;
+  }
+};
+
+// decode the whole file through the byte cursor (once per file, on a pool thread)
+void decode_tmp_file(TmpFile& f) {
+  ByteCursor c;
+  c.open(f);
+  c.set_name("");
+  f.recs.reserve(f.size / 19 + 16);  // (a record with a one-character name is 19 bytes)
+  uint16_t last = 0;
+  f.decoded = true;
+  while (c.next()) {
+    if (c.partial) {  // a short last record keeps, field by field, what the walk's variables held: left to the byte cursor of each walk
+      f.decoded = false;
+      f.recs = HugeVector<DecRec>();
+      return;
+    }
+    if (f.names[last] != c.chrom) {
+      size_t k = 0;
+      while (k < f.names.size() && f.names[k] != c.chrom) k++;
+      if (k == f.names.size()) {
+        if (f.names.size() >= 65535) {
+          f.decoded = false;
+          f.recs = HugeVector<DecRec>();
+          return;
+        }
+        f.names.emplace_back(c.chrom);
+      }
+      last = (uint16_t)k;
+    }
+    f.recs.push_back(DecRec{c.bp, c.AAF, c.DAF, last, c.anc, c.der});
+  }
+}
+
+// A pair's cursor into one file: the decoded records where there are any (the same sequence of states the byte cursor goes through),
+// else the bytes.
+struct Cursor {
+  const DecRec *r = nullptr, *rend = nullptr;
+  const TmpFile* file = nullptr;
+  ByteCursor bytes;
+  uint16_t chrom = 0;
+  int name_id = -1;       // index of the walk's chromosome among the file's names (-1: no record has it)
+  bool match = true;
+  int bp = 0, AAF = 0, DAF = 0;
+  char anc = 0, der = 0;
+  void open(const TmpFile& f) {
+    file = &f;
+    if (f.decoded) r = f.recs.data(), rend = r + f.recs.size();
+    else bytes.open(f);
+  }
+  void set_name(const char* n) {
+    if (!file->decoded) {
+      bytes.set_name(n);
+      match = bytes.match;
+      return;
+    }
+    name_id = -1;
+    for (size_t k = 0; k < file->names.size(); k++)
+      if (file->names[k] == n) name_id = (int)k;
+    match = (int)chrom == name_id;
+  }
+  bool next() {
+    if (!file->decoded) {
+      bytes.AAF = AAF, bytes.DAF = DAF;  // (the walk resets these between SNPs; a short last record keeps what it does not reach)
+      const bool ok = bytes.next();
+      bp = bytes.bp, AAF = bytes.AAF, DAF = bytes.DAF, anc = bytes.anc, der = bytes.der, match = bytes.match;
+      return ok;
+    }
+    if (r == rend) return false;
+    bp = r->bp, AAF = r->AAF, DAF = r->DAF, anc = r->anc, der = r->der, chrom = r->chrom;
+    match = (int)chrom == name_id;
+    r++;
+    return true;
   }
 };
 
@@ -989,7 +1078,13 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
         tmp_files[*path].reset(f);
         pool.submit([f] {
           const double t0 = now_s();
-          load_tmp_file(*f);
+          if (load_tmp_file(*f)) {
+            decode_tmp_file(*f);
+            if (f->decoded && f->data && f->size) {  // (the bytes are no longer needed)
+              ::munmap(const_cast<char*>(f->data), f->size);
+              f->data = nullptr;
+            }
+          }
           WorkSeconds::add(g_work.load_tmp, now_s() - t0);
         });
       }

@@ -215,6 +215,26 @@ def test_pairs_mode_counts_equal_separate_runs(tmp_path):
         assert (tmp_path / (out + ".counts")).read_text() == (tmp_path / (out + "_single.counts")).read_text()
 
 
+def test_pairs_with_a_file_that_ends_inside_a_record(tmp_path):
+    """A .colate.in that ends in the middle of a record: the reference's fread calls leave the fields they do not reach as they were
+    (coal.cpp:2126-2133).  The batched front end decodes every file once into fixed records -- but not such a file, whose last record
+    depends on what the walk's variables held: its walks go through the byte cursor, and the tables are those of the single-pair feeder."""
+    case = gl.l3_stage("l3_modern", str(tmp_path))
+    for name, cut in (("T.colate.in", 7), ("R.colate.in", 3)):
+        raw = (tmp_path / name).read_bytes()
+        (tmp_path / name).write_bytes(raw[:len(raw) - cut])
+    common = ["--mode", "mut", "--mut", "P", "--chr", "chr.txt", "--bins", "3,7,0.2", "--seed", "5", "--num_bootstraps", "2"]
+    specs = [("T.colate.in", "R.colate.in", "ab"), ("R.colate.in", "T.colate.in", "ba")]
+    (tmp_path / "pairs.txt").write_text("".join(" ".join(sp) + "\n" for sp in specs))
+    r = _run_cli(common + ["--pairs", "pairs.txt", "--counts_only"], str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    for tgt, ref, out in specs:
+        r = _run_cli(common + ["--target_tmp", tgt, "--reference_tmp", ref, "-o", out + "_single", "--counts_out", out + "_single.counts",
+                               "--counts_only"], str(tmp_path), env=dict(os.environ, COLATE_SINGLE_FEEDER="1"))
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        assert (tmp_path / (out + ".counts")).read_text() == (tmp_path / (out + "_single.counts")).read_text()
+
+
 def test_pairs_fixture_counts_reproduce_reference(tmp_path):
     """`--pairs` against the REFERENCE (fixture l3_pairs: Colate_ref run once per pair, same --seed): the count tables of
     every pair, through the oracle's EM, print exactly the .coal the reference wrote for that pair, with its iteration
