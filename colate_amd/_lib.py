@@ -17,6 +17,15 @@ if not os.path.exists(LIB_PATH):
         "(or `python -c 'import __graft_entry__ as g; g.build()'`). colate_amd has no CPU fallback."
     )
 
+# One HIP runtime per process.  A PyTorch-ROCm wheel carries its own libamdhip64 / libhsa-runtime64; libcolate_amd.so is linked
+# against the system's.  Whichever is loaded first serves both (same sonames) -- unless it is the system's: torch then still
+# loads its bundled copies by path, a second HSA runtime comes up in the process, finds the device taken and reports "No HIP GPUs
+# are available" (tools/study/hip_runtime_order.py).  So where torch is installed it goes first; nothing else of it is used here.
+try:
+    import torch  # noqa: F401
+except Exception:  # noqa: BLE001  (no torch: the system runtime is the only one)
+    pass
+
 lib = ctypes.CDLL(LIB_PATH)
 
 c_int = ctypes.c_int

@@ -24,16 +24,6 @@ def pytest_collection_modifyitems(config, items):
     except Exception:  # noqa: BLE001  (no library / no driver: same answer)
         have = False
     if have:
-        # torch's HIP runtime must come up before the library has done real work in this process: initialised late (a subset
-        # of the suite whose first torch call comes after other GPU tests) it reports "No HIP GPUs are available"; in the
-        # order of the whole suite the bench launcher's tests bring it up first, here it is made so for every selection
-        try:
-            import torch
-
-            if torch.cuda.is_available():
-                torch.cuda.init()
-        except Exception:  # noqa: BLE001  (tests that need torch say so themselves)
-            pass
         return
     skip = pytest.mark.skip(reason="no HIP device in this environment (run with -m gpu on the MI355X box)")
     for item in items:

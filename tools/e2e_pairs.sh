@@ -31,8 +31,8 @@ for run in ${RUNS:-host:default device:32 device:default}; do
   if [ "$threads" = default ]; then unset COLATE_THREADS; else export COLATE_THREADS=$threads; fi
   if [ "$fill" = host ]; then export COLATE_DEVICE_FILL=0; else unset COLATE_DEVICE_FILL; fi
   case "$fill" in device[0-9]*) export COLATE_UNIFORM_WINDOW_MB=${fill#device};; *) unset COLATE_UNIFORM_WINDOW_MB;; esac  # (deviceNNN: stream windows of NNN MB)
-  COLATE_TIMING=1 "$R/colate_amd/bin/Colate" $common --pairs pairs.txt > ours.out 2> ours.err
-  echo "colate_amd --pairs (age sampling on the $fill, COLATE_THREADS=$threads): $(since $t0) s wall for $P pairs x $B replicates"
+  COLATE_TIMING=1 ${PIN:+taskset -c $PIN} "$R/colate_amd/bin/Colate" $common --pairs pairs.txt > ours.out 2> ours.err
+  echo "colate_amd --pairs (age sampling on the $fill, COLATE_THREADS=$threads${PIN:+, taskset -c $PIN}): $(since $t0) s wall for $P pairs x $B replicates"
   grep '^Timing' ours.err | sed 's/^/    /'
 done
 unset COLATE_THREADS COLATE_DEVICE_FILL COLATE_UNIFORM_WINDOW_MB
