@@ -55,7 +55,7 @@ double now_s() { return StageTimes::now(); }
 
 // thread-seconds per kind of work (COLATE_TIMING=1 prints them)
 struct WorkSeconds {
-  std::atomic<double> parse_mut{0}, load_tmp{0}, walk{0}, sample{0};
+  std::atomic<double> parse_mut{0}, load_tmp{0}, index{0}, walk{0}, sample{0};
   static void add(std::atomic<double>& a, double dt) {
     double v = a.load();
     while (!a.compare_exchange_weak(v, v + dt)) {}
@@ -217,6 +217,19 @@ struct TmpFile {
   HugeVector<DecRec> recs;
   std::vector<std::string> names{std::string()};
   bool decoded = false;  // false: more than 65535 distinct names -- the walks decode the bytes themselves
+  // What a walk finds in this file, row by row of the .mut files, as far as it does not depend on the other sample of the pair
+  // (build_walk_index below): as the reference sample of a pair / as its target.
+  struct RefIdx {
+    int32_t prev_pass;  // position of the latest earlier row of the chromosome that passes as reference (-1: none)
+    uint16_t DAF, N;    // the record's DAF and DAF + AAF where the row passes the tests of coal.cpp:2181-2199, else 0, 0
+  };
+  struct TgtIdx {
+    int32_t prev_bp;    // position of the record in front of the row's (-2: the row's record is the chromosome's first, or there is none)
+    uint16_t DAF, AAF;  // the record's counts where position and alleles match (coal.cpp:2201-2219), else 0, 0
+  };
+  std::vector<HugeVector<RefIdx>> ref_idx;  // [chromosome][row]
+  std::vector<HugeVector<TgtIdx>> tgt_idx;
+  bool indexable = false, want_ref = false, want_tgt = false;
   TmpFile() = default;
   TmpFile(const TmpFile&) = delete;
   TmpFile& operator=(const TmpFile&) = delete;
@@ -369,6 +382,119 @@ struct Cursor {
     return true;
   }
 };
+
+// ------------------------------------------------------------------ what a pair's walk finds in one file, computed once per file
+// The walk of coal.cpp:2125-2243 steps two cursors through the two samples' records, row by row of the .mut file.  What it finds is
+// almost a property of each file alone.  For files in which every chromosome of the list is one run of records, the runs in the list's
+// order, positions strictly ascending -- and .mut rows with strictly ascending positions --:
+//   * the REFERENCE cursor is advanced at every row, whatever the target: the row passes iff the cursor had to move in this row's
+//     search (its DAF / AAF are reset in front of every search, coal.cpp:2182-2183, and only a record read now sets them again:
+//     a record reached while an earlier row was searched, or the chromosome's first, which the skip loop reads, gives DAF = 0),
+//     stops on a record of the row's position and alleles, and that record's DAF is not 0;
+//   * the TARGET cursor is advanced only at rows that passed as reference.  Its record for a row is the first at or behind the
+//     row's position; it counts iff position and alleles match and the cursor moved in this row's search, i.e. iff the record in
+//     front of it lies at or behind the latest earlier row that passed as reference (which that search had started from) -- a
+//     number of the target file (prev_bp) against a number of the reference file (prev_pass).
+// So a pair's walk is one pass over two 8-byte arrays instead of two cursor merges over 16-byte records with a name to track:
+// 100 pairs x 1 GB of streaming became 100 x 0.3 GB, and a few instructions per row.  Anything else (a chromosome missing in a file,
+// runs out of order, equal positions, a file that was not decoded, an empty chromosome name) keeps the cursors.
+struct WalkRows {
+  const std::vector<std::string>* names;
+  const std::vector<HugeVector<CompactRow>>* rows;
+  bool rows_ascend = false;
+};
+
+bool find_runs(const TmpFile& f, const std::vector<std::string>& names, std::vector<std::pair<size_t, size_t>>& runs) {
+  if (!f.decoded) return false;
+  const size_t C = names.size(), n = f.recs.size();
+  runs.assign(C, {0, 0});
+  std::vector<int> list_of(f.names.size(), -1);  // file's name index -> position in the list (-1: not listed)
+  for (size_t c = 0; c < C; c++) {
+    if (names[c].empty()) return false;
+    for (size_t d = 0; d < c; d++)
+      if (names[d] == names[c]) return false;
+    for (size_t k = 0; k < f.names.size(); k++)
+      if (f.names[k] == names[c]) list_of[k] = (int)c;
+  }
+  int last = -1;          // list position of the latest run of a listed chromosome
+  bool in_listed = false;  // inside such a run
+  for (size_t k = 0; k < n; k++) {
+    const bool starts = k == 0 || f.recs[k].chrom != f.recs[k - 1].chrom;
+    if (starts) {
+      if (in_listed) runs[(size_t)last].second = k;
+      const int li = list_of[f.recs[k].chrom];
+      in_listed = li >= 0;
+      if (in_listed) {
+        if (li <= last) return false;  // a second run of a chromosome, or the runs not in the list's order
+        last = li;
+        runs[(size_t)li].first = k;
+      }
+    } else if (in_listed && f.recs[k].bp <= f.recs[k - 1].bp) {
+      return false;
+    }
+  }
+  if (in_listed) runs[(size_t)last].second = n;
+  for (size_t c = 0; c < C; c++)
+    if (runs[c].second <= runs[c].first) return false;  // (a chromosome without records: the skip loop would run to the end of the file)
+  return true;
+}
+
+void build_walk_index(TmpFile& f, const WalkRows& w) {
+  f.indexable = false;
+  std::vector<std::pair<size_t, size_t>> runs;
+  if (!w.rows_ascend || !find_runs(f, *w.names, runs)) return;
+  const size_t C = w.names->size();
+  if (f.want_ref) f.ref_idx.assign(C, HugeVector<TmpFile::RefIdx>());
+  if (f.want_tgt) f.tgt_idx.assign(C, HugeVector<TmpFile::TgtIdx>());
+  for (size_t c = 0; c < C; c++) {
+    const HugeVector<CompactRow>& rr = (*w.rows)[c];
+    const DecRec* const R = f.recs.data();
+    const size_t b = runs[c].first, e = runs[c].second;
+    if (f.want_ref) {
+      HugeVector<TmpFile::RefIdx>& out = f.ref_idx[c];
+      out.resize(rr.size());
+      size_t k = b;  // the record the cursor is on: the chromosome's first, read by the skip loop (or by the overrun of the chromosome before)
+      int32_t prev_pass = -1;
+      bool off_end = false;
+      for (size_t i = 0; i < rr.size(); i++) {
+        TmpFile::RefIdx x{prev_pass, 0, 0};
+        if (!off_end) {
+          size_t k2 = k;
+          while (k2 < e && R[k2].bp < rr[i].pos) k2++;
+          if (k2 == e) {
+            off_end = true;  // the cursor has left the chromosome: no match for this row nor any later one
+          } else {
+            if (k2 > k && R[k2].bp == rr[i].pos && R[k2].anc == rr[i].anc && R[k2].der == rr[i].der && R[k2].DAF != 0) {
+              const long long N = (long long)R[k2].DAF + R[k2].AAF;
+              if (R[k2].DAF < 0 || R[k2].DAF > 65535 || N <= 0 || N > 65535) return;  // (counts beyond the index's fields: cursors)
+              x.DAF = (uint16_t)R[k2].DAF, x.N = (uint16_t)N;
+              prev_pass = rr[i].pos;
+            }
+            k = k2;
+          }
+        }
+        out[i] = x;
+      }
+    }
+    if (f.want_tgt) {
+      HugeVector<TmpFile::TgtIdx>& out = f.tgt_idx[c];
+      out.resize(rr.size());
+      size_t k = b;
+      for (size_t i = 0; i < rr.size(); i++) {
+        while (k < e && R[k].bp < rr[i].pos) k++;
+        TmpFile::TgtIdx x{-2, 0, 0};
+        if (k < e && k > b) x.prev_bp = R[k - 1].bp;
+        if (k < e && R[k].bp == rr[i].pos && R[k].anc == rr[i].anc && R[k].der == rr[i].der) {
+          if (R[k].DAF < 0 || R[k].DAF > 65535 || R[k].AAF < 0 || R[k].AAF > 65535) return;
+          x.DAF = (uint16_t)R[k].DAF, x.AAF = (uint16_t)R[k].AAF;
+        }
+        if (x.prev_bp < -2) return;  // (negative positions: cursors)
+        out[i] = x;
+      }
+    }
+  }
+  f.indexable = true;
+}
 
 // ------------------------------------------------------------------ the uniform stream of the seed, generated once
 // std::uniform_real_distribution<double>(0, 1) on std::mt19937 = generate_canonical<double, 53>: two 32-bit draws per value
@@ -726,6 +852,7 @@ struct Engine {
   BinSnpFn bin_snp = nullptr;  // the vector form of the 100 bins of a SNP where the CPU has one (and the table passed its self-check)
   AddSnpFn add_snp = nullptr;  // ... and of the additions
   DevQueue* devq = nullptr;    // not null: the sampling runs on the device (fill_device.h)
+  bool use_index = true;       // walk through the per-file indices where both files of a pair have one (build_walk_index)
 
   // the 100 draws of every SNP of one genome-block segment, in order (coal.cpp:2260-2273, 2279-2295)
   void sample(PairFill& pf, Block& b, const std::vector<UsedSnp>& snps, uint64_t off) const {
@@ -840,6 +967,45 @@ struct Engine {
     if (pf.blk >= pf.blocks.size()) pf.blocks.emplace_back(new Block(A));
   }
 
+  // a SNP the pair uses (coal.cpp:2221-2297): its genome block, the row-0 entries of the F tables, and its 100 draws queued
+  void use_snp(PairFill& pf, const CompactRow& m, int tgt_DAF, int tgt_AAF, int DAF_ref, int N_ref) const {
+    const float num_samples = 100;
+    const double age = 0, ref_age = 0;  // forced, coal.cpp:2074-2075
+    const int bp_mut = m.pos;
+    const int N_target = tgt_DAF + tgt_AAF;
+    double age_begin = m.age_begin;
+    if (age_begin < ref_age) age_begin = ref_age;
+    while (pf.current_block_base + num_bases_per_block < bp_mut) {  // coal.cpp:2227-2234
+      pf.current_block_base += num_bases_per_block;
+      advance_block(pf);
+    }
+    // target genotype rounded to a diploid call, in float (coal.cpp:2236-2242)
+    float f_DAF_target = tgt_DAF, f_AAF_target = tgt_AAF;
+    f_DAF_target /= N_target / 2.0;
+    f_AAF_target /= N_target / 2.0;
+    f_DAF_target = std::round(f_DAF_target);
+    f_AAF_target = std::round(f_AAF_target);
+    if (pf.pending.empty()) pf.pending_off = pf.off;
+    if (devq && pf.dev_cur.empty()) pf.dev_cur_off = pf.off;
+    if (age_begin <= age) {  // coal.cpp:2245-2275
+      const int bin2 = age_bin_index(m.age_end, C);
+      if (bin2 < A) {  // row 0 of the A*A table; larger indices land in rows nobody reads
+        double* t = pf.blocks[pf.blk]->t.data();
+        t[2 * A + bin2] += f_DAF_target * DAF_ref / ((double)N_ref);
+        t[3 * A + bin2] += f_AAF_target * DAF_ref / ((double)N_ref);
+      }
+      const double w_ns = f_AAF_target * DAF_ref / ((double)N_ref * num_samples);
+      if (devq) pf.dev_cur.push_back(FillRec{(float)age_begin, m.age_end, 0.0, w_ns});  // (age_begin: a float, or the sample age 0)
+      else pf.pending.push_back(UsedSnp{age_begin, (double)m.age_end, 0.0, w_ns, true});
+    } else {  // coal.cpp:2277-2297
+      const double w_sh = f_DAF_target * DAF_ref / ((double)N_ref * num_samples), w_ns = f_AAF_target * DAF_ref / ((double)N_ref * num_samples);
+      if (devq) pf.dev_cur.push_back(FillRec{(float)age_begin, m.age_end, w_sh, w_ns});
+      else pf.pending.push_back(UsedSnp{age_begin, (double)m.age_end, w_sh, w_ns, false});
+    }
+    pf.off += 100;
+    pf.used_snps++;
+  }
+
   // Walks on until the pair has taken `limit` uniforms or its SNPs are exhausted.  The test sits in front of a row, before
   // either stream is touched for it, so the walk resumes exactly where it stopped.
   void walk(PairFill& pf, uint64_t limit) const {
@@ -848,27 +1014,47 @@ struct Engine {
     WorkSeconds::add(g_work.walk, now_s() - t_walk0 - (pf.inline_sample_s - sample0));
   }
   void walk_impl(PairFill& pf, uint64_t limit) const {
-    const float num_samples = 100;
-    const double age = 0, ref_age = 0;  // forced, coal.cpp:2074-2075
     Cursor& tgt = pf.tgt;
     Cursor& ref = pf.ref;
     if (pf.blocks.empty()) pf.blocks.emplace_back(new Block(A));
     while (pf.chr < rows.size()) {
       if (pf.redo.load(std::memory_order_relaxed)) break;
+      const bool indexed = use_index && pf.ref_file->indexable && pf.tgt_file->indexable;
       if (!pf.chr_open) {
         pf.current_block_base = 0;
-        ref.set_name(chr_names[pf.chr].c_str());
-        tgt.set_name(chr_names[pf.chr].c_str());
-        while (!ref.match) {  // skip to this chromosome, coal.cpp:2125-2134
-          if (!ref.next()) break;
-        }
-        while (!tgt.match) {
-          if (!tgt.next()) break;
+        if (!indexed) {
+          ref.set_name(chr_names[pf.chr].c_str());
+          tgt.set_name(chr_names[pf.chr].c_str());
+          while (!ref.match) {  // skip to this chromosome, coal.cpp:2125-2134
+            if (!ref.next()) break;
+          }
+          while (!tgt.match) {
+            if (!tgt.next()) break;
+          }
         }
         pf.row = 0;
         pf.chr_open = true;
       }
       const HugeVector<CompactRow>& rr = rows[pf.chr];
+      if (indexed) {  // what the two cursors would find, from the two files' indices (build_walk_index)
+        const TmpFile::RefIdx* const RI = pf.ref_file->ref_idx[pf.chr].data();
+        const TmpFile::TgtIdx* const TI = pf.tgt_file->tgt_idx[pf.chr].data();
+        for (; pf.row < rr.size(); pf.row++) {
+          if (pf.off >= limit) {
+            flush(pf);
+            return;
+          }
+          const TmpFile::RefIdx r = RI[pf.row];
+          if (r.N == 0) continue;  // the reference sample does not carry the derived allele here (or its record was read too early)
+          const TmpFile::TgtIdx t = TI[pf.row];
+          if ((t.DAF | t.AAF) == 0 || r.prev_pass > t.prev_bp) continue;  // no target record here -- or one that an earlier search had reached
+          use_snp(pf, rr[pf.row], t.DAF, t.AAF, r.DAF, r.N);
+        }
+        advance_block(pf);
+        pf.chr++;
+        pf.chr_open = false;
+        continue;
+      }
       for (; pf.row < rr.size(); pf.row++) {
         if (pf.off >= limit) {
           flush(pf);
@@ -898,38 +1084,7 @@ struct Engine {
         if (N_target == 0) use = false;
         if (!use) continue;
 
-        double age_begin = m.age_begin;
-        if (age_begin < ref_age) age_begin = ref_age;
-        while (pf.current_block_base + num_bases_per_block < bp_mut) {  // coal.cpp:2227-2234
-          pf.current_block_base += num_bases_per_block;
-          advance_block(pf);
-        }
-        // target genotype rounded to a diploid call, in float (coal.cpp:2236-2242)
-        float f_DAF_target = tgt.DAF, f_AAF_target = tgt.AAF;
-        f_DAF_target /= N_target / 2.0;
-        f_AAF_target /= N_target / 2.0;
-        f_DAF_target = std::round(f_DAF_target);
-        f_AAF_target = std::round(f_AAF_target);
-        const int DAF_ref = ref.DAF;
-        if (pf.pending.empty()) pf.pending_off = pf.off;
-        if (devq && pf.dev_cur.empty()) pf.dev_cur_off = pf.off;
-        if (age_begin <= age) {  // coal.cpp:2245-2275
-          const int bin2 = age_bin_index(m.age_end, C);
-          if (bin2 < A) {  // row 0 of the A*A table; larger indices land in rows nobody reads
-            double* t = pf.blocks[pf.blk]->t.data();
-            t[2 * A + bin2] += f_DAF_target * DAF_ref / ((double)N_ref);
-            t[3 * A + bin2] += f_AAF_target * DAF_ref / ((double)N_ref);
-          }
-          const double w_ns = f_AAF_target * DAF_ref / ((double)N_ref * num_samples);
-          if (devq) pf.dev_cur.push_back(FillRec{(float)age_begin, m.age_end, 0.0, w_ns});  // (age_begin: a float, or the sample age 0)
-          else pf.pending.push_back(UsedSnp{age_begin, (double)m.age_end, 0.0, w_ns, true});
-        } else {  // coal.cpp:2277-2297
-          const double w_sh = f_DAF_target * DAF_ref / ((double)N_ref * num_samples), w_ns = f_AAF_target * DAF_ref / ((double)N_ref * num_samples);
-          if (devq) pf.dev_cur.push_back(FillRec{(float)age_begin, m.age_end, w_sh, w_ns});
-          else pf.pending.push_back(UsedSnp{age_begin, (double)m.age_end, w_sh, w_ns, false});
-        }
-        pf.off += 100;
-        pf.used_snps++;
+        use_snp(pf, m, tgt.DAF, tgt.AAF, ref.DAF, N_ref);
       }
       advance_block(pf);  // chromosome end, coal.cpp:2306-2310
       pf.chr++;
@@ -1100,6 +1255,26 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
   pool.wait_idle();
   for (auto& kv : tmp_files)
     if (!kv.second->ok) std::cerr << "Failed to open " << kv.first << std::endl;  // (the reference goes on and reads nothing)
+  // ---- what the walks find in each file, once per file (build_walk_index)
+  const char* e_idx = std::getenv("COLATE_INDEXED_WALK");
+  const bool use_index = !(e_idx && std::atoi(e_idx) == 0);
+  size_t n_indexed = 0;
+  if (use_index) {
+    WalkRows wr{&names, &rows, true};
+    for (const HugeVector<CompactRow>& r : rows)
+      for (size_t i = 1; i < r.size() && wr.rows_ascend; i++) wr.rows_ascend = r[i].pos > r[i - 1].pos && r[i - 1].pos >= 0;
+    for (size_t p : todo) tmp_files[pairs[p].target]->want_tgt = true, tmp_files[pairs[p].reference]->want_ref = true;
+    for (auto& kv : tmp_files) {
+      TmpFile* f = kv.second.get();
+      if (f->ok) pool.submit([f, wr] {
+        const double t0 = now_s();
+        build_walk_index(*f, wr);
+        WorkSeconds::add(g_work.index, now_s() - t0);
+      });
+    }
+    pool.wait_idle();
+    for (auto& kv : tmp_files) n_indexed += kv.second->indexable ? 1 : 0;
+  }
   const double t1 = now_s();
   size_t n_rows = 0, n_kept = 0, n_rec = 0;
   for (size_t c = 0; c < rows.size(); c++) n_rows += rows_total[c], n_kept += rows[c].size();
@@ -1129,7 +1304,7 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
     }
   }
   Engine eng{names, rows, A, C, num_bases_per_block, stream, fastbin, pool, fastbin.ok() ? pick_bin_snp() : nullptr, fastbin.ok() ? pick_add_snp() : nullptr,
-             dev_pending ? &devq : nullptr};
+             dev_pending ? &devq : nullptr, use_index};
   std::vector<std::unique_ptr<PairFill>> fills;
   for (size_t p : todo) {
     fills.emplace_back(new PairFill);
@@ -1275,7 +1450,8 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
               << t1 - t0 << " s; " << todo.size() << " pairs filled in " << t2 - t1 << " s (" << used << " used SNPs, " << windows
               << " stream window(s) of " << window_mb << " MB, waited " << stream.waited() << " thread-s for uniforms, " << redone
               << " pair(s) redone sequentially in " << now_s() - t2 << " s); thread-seconds: .mut parse " << g_work.parse_mut.load()
-              << ", .colate.in decode " << g_work.load_tmp.load() << ", SNP walks " << g_work.walk.load() << ", age sampling "
+              << ", .colate.in decode " << g_work.load_tmp.load() << ", walk indices " << g_work.index.load() << " (" << n_indexed << " of "
+              << tmp_files.size() << " files)" << ", SNP walks " << g_work.walk.load() << ", age sampling "
               << g_work.sample.load()
               << (dev ? "; age sampling on the GPU: " + std::to_string(dev_jobs) + " (pair, block) jobs, " + std::to_string(dev_recs) + " SNPs in " + std::to_string(dev_launches) + " launches, " +
                             std::to_string(dev->gpu_seconds()) + " s of copies and kernels, " + std::to_string(dev_upload_s) + " s uploading the uniform stream, " + std::to_string(dev_make_s) + " s setting up, " + std::to_string(dev_staging_s) + " s page-locking the record buffers beside the first windows, " +

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import golden_lib as gl
+import synth_files
 import oracle_lib as ol
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -233,6 +234,50 @@ def test_pairs_with_a_file_that_ends_inside_a_record(tmp_path):
                                "--counts_only"], str(tmp_path), env=dict(os.environ, COLATE_SINGLE_FEEDER="1"))
         assert r.returncode == 0, r.stderr.decode()[-800:]
         assert (tmp_path / (out + ".counts")).read_text() == (tmp_path / (out + "_single.counts")).read_text()
+
+
+def _drop_out_of_order_records(path):
+    """Rewrites a .colate.in without the records whose position does not exceed that of the record in front of them (same chromosome)."""
+    import struct
+    b = open(path, "rb").read()
+    i, out, last = 0, bytearray(), None
+    while i + 4 <= len(b):
+        (l,) = struct.unpack_from("<i", b, i)
+        name = b[i + 4:i + 4 + l]
+        (bp,) = struct.unpack_from("<i", b, i + 4 + l)
+        rec = b[i:i + 4 + l + 14]
+        i += 4 + l + 14
+        if last is not None and last[0] == name and bp <= last[1]:
+            continue
+        out += rec
+        last = (name, bp)
+    open(path, "wb").write(bytes(out))
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_indexed_walk_equals_the_cursor_walk(tmp_path, seed):
+    """Where every file of a pair is well-formed (each chromosome one run of records in ascending positions) the batched front end walks
+    through per-file indices instead of the two cursors of coal.cpp:2125-2243 -- same used SNPs, same tables: against the cursor walk
+    (COLATE_INDEXED_WALK=0, the code the reference-made fixtures pin) on inputs with absent records, allele mismatches, DAF = 0 and rows
+    whose record an earlier row's search had already reached, three targets x two references, several stream windows."""
+    d = str(tmp_path)
+    synth_files.write_inputs(d, chroms=("1", "2", "3", "4"), snps_per_chr=6000, seed=seed, span=70_000_000, extra_targets=2, extra_refs=1)
+    for f in ("T", "T1", "T2", "R", "R1"):
+        _drop_out_of_order_records(os.path.join(d, f + ".colate.in"))
+    pairs = [(f"{t}.colate.in", f"{r}.colate.in", f"out_{t}_{r}") for t in ("T", "T1", "T2") for r in ("R", "R1")]
+    (tmp_path / "pairs.txt").write_text("".join(" ".join(p) + "\n" for p in pairs))
+    args = ["--mode", "mut", "--mut", "P", "--chr", "chr.txt", "--bins", "3,7,0.2", "--seed", "4", "--num_bootstraps", "2", "--pairs", "pairs.txt", "--counts_only"]
+    env = dict(os.environ, COLATE_TIMING="1", COLATE_UNIFORM_WINDOW_MB="4")
+    r = _run_cli(args, d, env=dict(env, COLATE_INDEXED_WALK="0"))
+    assert r.returncode == 0 and "(0 of 5 files)" in r.stderr.decode(), r.stderr.decode()[-800:]
+    want = {p[2]: (tmp_path / (p[2] + ".counts")).read_bytes() for p in pairs}
+    for p in pairs:
+        os.remove(tmp_path / (p[2] + ".counts"))
+    r = _run_cli(args, d, env=env)
+    assert r.returncode == 0 and "(5 of 5 files)" in r.stderr.decode(), r.stderr.decode()[-800:]
+    for p in pairs:
+        assert (tmp_path / (p[2] + ".counts")).read_bytes() == want[p[2]], p[2]
+    assert len(set(want.values())) == len(pairs)  # (six different pairs, six different tables)
 
 
 def test_pairs_fixture_counts_reproduce_reference(tmp_path):
