@@ -386,7 +386,7 @@ struct Cursor {
 // ------------------------------------------------------------------ what a pair's walk finds in one file, computed once per file
 // The walk of coal.cpp:2125-2243 steps two cursors through the two samples' records, row by row of the .mut file.  What it finds is
 // almost a property of each file alone.  For files in which every chromosome of the list is one run of records, the runs in the list's
-// order, positions strictly ascending -- and .mut rows with strictly ascending positions --:
+// order, positions not descending -- and .mut rows whose positions do not descend --:
 //   * the REFERENCE cursor is advanced at every row, whatever the target: the row passes iff the cursor had to move in this row's
 //     search (its DAF / AAF are reset in front of every search, coal.cpp:2182-2183, and only a record read now sets them again:
 //     a record reached while an earlier row was searched, or the chromosome's first, which the skip loop reads, gives DAF = 0),
@@ -397,7 +397,7 @@ struct Cursor {
 //     number of the target file (prev_bp) against a number of the reference file (prev_pass).
 // So a pair's walk is one pass over two 8-byte arrays instead of two cursor merges over 16-byte records with a name to track:
 // 100 pairs x 1 GB of streaming became 100 x 0.3 GB, and a few instructions per row.  Anything else (a chromosome missing in a file,
-// runs out of order, equal positions, a file that was not decoded, an empty chromosome name) keeps the cursors.
+// runs out of order, a position below the one in front of it, a file that was not decoded, an empty chromosome name) keeps the cursors.
 struct WalkRows {
   const std::vector<std::string>* names;
   const std::vector<HugeVector<CompactRow>>* rows;
@@ -429,8 +429,8 @@ bool find_runs(const TmpFile& f, const std::vector<std::string>& names, std::vec
         last = li;
         runs[(size_t)li].first = k;
       }
-    } else if (in_listed && f.recs[k].bp <= f.recs[k - 1].bp) {
-      return false;
+    } else if (in_listed && f.recs[k].bp < f.recs[k - 1].bp) {
+      return false;  // (equal positions are fine: a cursor stops at the first of them, and so do the indices)
     }
   }
   if (in_listed) runs[(size_t)last].second = n;
@@ -1262,7 +1262,7 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
   if (use_index) {
     WalkRows wr{&names, &rows, true};
     for (const HugeVector<CompactRow>& r : rows)
-      for (size_t i = 1; i < r.size() && wr.rows_ascend; i++) wr.rows_ascend = r[i].pos > r[i - 1].pos && r[i - 1].pos >= 0;
+      for (size_t i = 1; i < r.size() && wr.rows_ascend; i++) wr.rows_ascend = r[i].pos >= r[i - 1].pos && r[i - 1].pos >= 0;
     for (size_t p : todo) tmp_files[pairs[p].target]->want_tgt = true, tmp_files[pairs[p].reference]->want_ref = true;
     for (auto& kv : tmp_files) {
       TmpFile* f = kv.second.get();

@@ -236,8 +236,9 @@ def test_pairs_with_a_file_that_ends_inside_a_record(tmp_path):
         assert (tmp_path / (out + ".counts")).read_text() == (tmp_path / (out + "_single.counts")).read_text()
 
 
-def _drop_out_of_order_records(path):
-    """Rewrites a .colate.in without the records whose position does not exceed that of the record in front of them (same chromosome)."""
+def _drop_out_of_order_records(path, dup_every=0):
+    """Rewrites a .colate.in without the records whose position lies below that of the record in front of them (same chromosome);
+    `dup_every`: every so many records one is written twice with other counts (equal positions are within what the indices handle)."""
     import struct
     b = open(path, "rb").read()
     i, out, last = 0, bytearray(), None
@@ -247,10 +248,14 @@ def _drop_out_of_order_records(path):
         (bp,) = struct.unpack_from("<i", b, i + 4 + l)
         rec = b[i:i + 4 + l + 14]
         i += 4 + l + 14
-        if last is not None and last[0] == name and bp <= last[1]:
+        if last is not None and last[0] == name and bp < last[1]:
             continue
         out += rec
         last = (name, bp)
+        n_out = getattr(_drop_out_of_order_records, "_n", 0) + 1
+        _drop_out_of_order_records._n = n_out
+        if dup_every and n_out % dup_every == 0:
+            out += rec[:-8] + struct.pack("<ii", 1, 1)  # the same site again, AAF = DAF = 1
     open(path, "wb").write(bytes(out))
 
 
@@ -263,7 +268,7 @@ def test_indexed_walk_equals_the_cursor_walk(tmp_path, seed):
     d = str(tmp_path)
     synth_files.write_inputs(d, chroms=("1", "2", "3", "4"), snps_per_chr=6000, seed=seed, span=70_000_000, extra_targets=2, extra_refs=1)
     for f in ("T", "T1", "T2", "R", "R1"):
-        _drop_out_of_order_records(os.path.join(d, f + ".colate.in"))
+        _drop_out_of_order_records(os.path.join(d, f + ".colate.in"), dup_every=37 if seed != 11 else 0)
     pairs = [(f"{t}.colate.in", f"{r}.colate.in", f"out_{t}_{r}") for t in ("T", "T1", "T2") for r in ("R", "R1")]
     (tmp_path / "pairs.txt").write_text("".join(" ".join(p) + "\n" for p in pairs))
     args = ["--mode", "mut", "--mut", "P", "--chr", "chr.txt", "--bins", "3,7,0.2", "--seed", "4", "--num_bootstraps", "2", "--pairs", "pairs.txt", "--counts_only"]
