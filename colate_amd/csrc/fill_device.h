@@ -49,8 +49,10 @@ class DeviceFill {
   // page-locks a host buffer the uniforms will be uploaded from (the ring of the stream's producer): pageable memory goes through
   // a staging copy at a few GB/s, 6 GB of uniforms are then seconds of wall time.  Failure is not an error (the upload works either way).
   void pin(void* p, size_t bytes);
-  // uniforms [off, off + n) of the stream (any host memory); returns when the source may be reused
+  // uniforms [off, off + n) of the stream: the copy is enqueued (launches submitted later wait for it on the device); the source may
+  // be reused after sync_uploads()
   bool upload_uniforms(uint64_t off, const double* src, size_t n);
+  bool sync_uploads();
   // records staging()[0 .. nrecs) and the jobs that refer to them: copied and launched asynchronously; staging() is another buffer afterwards
   bool submit(const std::vector<FillJob>& jobs, size_t nrecs);
   // waits for everything; tables [max_tables][2][A]; flags per table: 1 = a sample needs the host (guard band, redraw, range): redo the pair
@@ -71,6 +73,8 @@ class DeviceFill {
   FillJob* d_jobs_[2] = {nullptr, nullptr};
   void* stream_[2] = {nullptr, nullptr};
   void* copy_stream_ = nullptr;
+  void* upload_ev_ = nullptr;
+  bool uploads_pending_ = false;
   void* ev_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // per buffer: start / end of its latest launch
   bool launched_[2] = {false, false};
   double gpu_s_ = 0;

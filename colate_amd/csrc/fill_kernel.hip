@@ -16,10 +16,12 @@ constexpr int kJobsPerBlock = 4;   // one wave per job
 constexpr int kDraws = 100;        // coal.cpp:2073 num_samples
 
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// orders this wave's LDS accesses (the histogram) -- and only those: a fence over all address spaces waits for the global loads too
+// (s_waitcnt vmcnt(0)), i.e. for the next SNP's record and uniforms, which are fetched ahead precisely so that nobody waits for them
 __device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 // One wave per job = the used SNPs of one (pair, genome block) in file order.  The loop is uniform over the wave: a SNP's record
@@ -28,21 +30,21 @@ __global__ __launch_bounds__(kJobsPerBlock* kWave) void fill_sample_kernel(const
                                                                             const FillRec* __restrict__ recs, const double* __restrict__ U,
                                                                             const double* __restrict__ g_lo, const double* __restrict__ g_hi,
                                                                             int A, double* __restrict__ tables, int* __restrict__ flags) {
-  __shared__ double s_lo[kSlots * kWave + 2], s_hi[kSlots * kWave + 2];  // guard band edges of step k = 1..A ([0] = -inf, [A + 1] = +inf)
+  __shared__ double2 s_band[kSlots * kWave + 2];  // (lower, upper) edge of the guard band around step k = 1..A ([0] = -inf, [A + 1] = +inf)
   __shared__ unsigned s_hist[kJobsPerBlock][kSlots * kWave];
-  for (int i = threadIdx.x; i < A + 2; i += blockDim.x) s_lo[i] = g_lo[i], s_hi[i] = g_hi[i];
+  for (int i = threadIdx.x; i < A + 2; i += blockDim.x) s_band[i] = make_double2(g_lo[i], g_hi[i]);
   __syncthreads();  // (the only workgroup barrier: the waves of a block are independent jobs from here on)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = blockIdx.x * kJobsPerBlock + wave;
   if (j >= njobs) return;
   const FillJob job = jobs[j];
-  volatile unsigned* hist = s_hist[wave];
+  unsigned* const hist = s_hist[wave];  // (accessed through wavefront-scope atomics between LDS-only fences: a `volatile` pointer made every access wait for the global loads in flight)
   double* const T = tables + (size_t)job.table * 2 * (size_t)A;
   double sh[kSlots], ns[kSlots];
 #pragma unroll
   for (int s = 0; s < kSlots; s++) {
     const int b = lane + kWave * s;
-    hist[b] = 0u;
+    __hip_atomic_store(&hist[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     sh[s] = b < A ? T[b] : 0.0;
     ns[s] = b < A ? T[A + b] : 0.0;
   }
@@ -71,45 +73,45 @@ __global__ __launch_bounds__(kJobsPerBlock* kWave) void fill_sample_kernel(const
     const double begin = (double)fb, end = (double)fe;
     const double span = end - begin;
     const bool emp = !(begin > 0.0);  // age_begin <= age, coal.cpp:2245
-    // every sample lies in [begin, fl(span + begin)] (u in [0, 1), rounding is monotone): the steps whose whole band is at or
-    // below `begin` are at or below every sample, the steps whose band starts above the largest sample above every sample
-    const double top = __dadd_rn(span, begin);
-    const double xmax = __longlong_as_double(__double_as_longlong(top) + 1);  // (>= 0, finite: the next double up)
-    int s0 = 0, s1 = 0;
-#pragma unroll
-    for (int s = 0; s < kSlots; s++) {
-      const int k = lane + kWave * s + 1;
-      const bool in = k <= A;
-      const double hk = s_hi[in ? k : 0], lk = s_lo[in ? k : 0];
-      s0 += __popcll(ballot64(in && hk <= begin));
-      s1 += __popcll(ballot64(in && lk <= xmax));
-    }
     // the samples (coal.cpp:2262, 2281: a separate multiply and add)
     const double x0 = __dadd_rn(__dmul_rn(u0, span), begin);
     const double x1 = v1 ? __dadd_rn(__dmul_rn(u1, span), begin) : begin;
-    int c0h = 0, c0l = 0, c1h = 0, c1l = 0;
-    for (int k = s0 + 1; k <= s1; k++) {  // (uniform bounds)
-      const double hk = s_hi[k], lk = s_lo[k];
-      c0h += x0 >= hk ? 1 : 0;
-      c0l += x0 >= lk ? 1 : 0;
-      c1h += x1 >= hk ? 1 : 0;
-      c1l += x1 >= lk ? 1 : 0;
-    }
-    const int b0 = s0 + c0h, b1 = s0 + c1h;  // bin(x) = #{k : hi(k) <= x} for every x outside all bands
-    // inside a band (the two counts differ), or -- not the F path -- beyond the grid, where the reference draws again and the stream
+    // bin(x) = #{k : upper edge of band k <= x} for every x outside all bands.  A candidate from a single-precision logarithm
+    // (bin k is centred on exp((k - 1) / 10) / 10), settled by the four bands around it: inside a band, or further off than one
+    // step -- the host decides.  (Counting the steps between the bins of `begin` and of the largest possible sample, one LDS
+    // round trip each, was a third of the kernel's time; for the F path, whose ranges start at 0, seventy steps.)
+    auto settle = [&](double x, bool& unsure) -> int {
+      int c = (int)rintf(6.9314718f * __log2f((float)x * 10.0f)) + 1;  // (x = 0: -inf -> clamped)
+      c = c < 0 ? 0 : (c > A ? A : c);
+      const double2 bm = s_band[c > 0 ? c - 1 : 0], b0_ = s_band[c], bp = s_band[c + 1], bq = s_band[c + 2 <= A + 1 ? c + 2 : A + 1];
+      int b;
+      bool ok;
+      if (x >= bp.y) {            // at or beyond the upper edge of step c + 1
+        b = c + 1, ok = x < bq.x;
+      } else if (x >= b0_.y) {    // ... of step c (c = 0: -inf)
+        b = c, ok = x < bp.x;
+      } else {                    // below step c
+        b = c - 1, ok = x < b0_.x && x >= bm.y;
+      }
+      unsure = !ok;
+      return b < 0 ? 0 : b;
+    };
+    bool un0, un1;
+    const int b0 = settle(x0, un0), b1 = settle(x1, un1);
+    // inside a band, or -- not the F path -- beyond the grid, where the reference draws again and the stream
     // no longer lines up: the host decides (the whole pair is filled again there)
-    bool trouble = (c0h != c0l) || (v1 && c1h != c1l);
+    bool trouble = un0 || (v1 && un1);
     if (!emp) trouble = trouble || b0 >= A || (v1 && b1 >= A) || x0 < 0.0 || (v1 && x1 < 0.0);
     if (ballot64(trouble) != 0ull) bad = 1;
     // how many samples fell into each bin (integers: the order does not matter) ...
-    if (b0 < A) atomicAdd(const_cast<unsigned*>(&hist[b0]), 1u);
-    if (v1 && b1 < A) atomicAdd(const_cast<unsigned*>(&hist[b1]), 1u);
+    if (b0 < A) __hip_atomic_fetch_add(&hist[b0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (v1 && b1 < A) __hip_atomic_fetch_add(&hist[b1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     wave_lds_fence();
     unsigned cnt[kSlots];
 #pragma unroll
     for (int s = 0; s < kSlots; s++) {
-      cnt[s] = hist[lane + kWave * s];
-      hist[lane + kWave * s] = 0u;
+      cnt[s] = __hip_atomic_load(&hist[lane + kWave * s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      __hip_atomic_store(&hist[lane + kWave * s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     wave_lds_fence();
     // ... and that many additions of the SNP's weight to the bin, one after the other (what the sample-by-sample loop of the
@@ -206,6 +208,9 @@ DeviceFill* DeviceFill::create(int device, int A, const double* guard_lo, const 
     hipStream_t cs;
     if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return o.fail("hipStreamCreate", (int)hipGetLastError());
     o.copy_stream_ = cs;
+    hipEvent_t ue;
+    if (hipEventCreateWithFlags(&ue, hipEventDisableTiming) != hipSuccess) return o.fail("hipEventCreate", (int)hipGetLastError());
+    o.upload_ev_ = ue;
     return true;
   };
   if (!init()) {
@@ -229,6 +234,8 @@ DeviceFill::~DeviceFill() {
       if (ev_[b][k]) (void)hipEventDestroy((hipEvent_t)ev_[b][k]);
     if (stream_[b]) (void)hipStreamDestroy((hipStream_t)stream_[b]);
   }
+  if (copy_stream_) (void)hipStreamSynchronize((hipStream_t)copy_stream_);
+  if (upload_ev_) (void)hipEventDestroy((hipEvent_t)upload_ev_);
   if (copy_stream_) (void)hipStreamDestroy((hipStream_t)copy_stream_);
   for (void* p : {(void*)d_u_, (void*)d_lo_, (void*)d_hi_, (void*)d_tables_, (void*)d_flags_})
     if (p) (void)hipFree(p);
@@ -263,7 +270,15 @@ bool DeviceFill::upload_uniforms(uint64_t off, const double* src, size_t n) {
   }
   FILL_TRY(hipSetDevice(device_));
   FILL_TRY(hipMemcpyAsync(d_u_ + off, src, n * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)copy_stream_));
+  uploads_pending_ = true;
+  return true;
+}
+
+bool DeviceFill::sync_uploads() {
+  if (!uploads_pending_) return true;
+  FILL_TRY(hipSetDevice(device_));
   FILL_TRY(hipStreamSynchronize((hipStream_t)copy_stream_));
+  uploads_pending_ = false;
   return true;
 }
 
@@ -276,6 +291,10 @@ bool DeviceFill::submit(const std::vector<FillJob>& jobs, size_t nrecs) {
   FILL_TRY(hipSetDevice(device_));
   const int b = cur_;
   hipStream_t s = (hipStream_t)stream_[b];
+  if (uploads_pending_) {  // the launch reads uniforms whose copies may still be in flight on the copy stream
+    FILL_TRY(hipEventRecord((hipEvent_t)upload_ev_, (hipStream_t)copy_stream_));
+    FILL_TRY(hipStreamWaitEvent(s, (hipEvent_t)upload_ev_, 0));
+  }
   std::memcpy(h_jobs_[b], jobs.data(), jobs.size() * sizeof(FillJob));
   FILL_TRY(hipMemcpyAsync(d_recs_[b], stage_[b], nrecs * sizeof(FillRec), hipMemcpyHostToDevice, s));
   FILL_TRY(hipMemcpyAsync(d_jobs_[b], h_jobs_[b], jobs.size() * sizeof(FillJob), hipMemcpyHostToDevice, s));
@@ -300,6 +319,7 @@ bool DeviceFill::submit(const std::vector<FillJob>& jobs, size_t nrecs) {
 
 bool DeviceFill::finish(std::vector<double>& tables, std::vector<int>& flags) {
   FILL_TRY(hipSetDevice(device_));
+  if (!sync_uploads()) return false;
   for (int b = 0; b < 2; b++) {
     FILL_TRY(hipStreamSynchronize((hipStream_t)stream_[b]));
     if (launched_[b]) {

@@ -1381,8 +1381,12 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
     if (!any) break;
     pool.wait_idle();
     if (dev && !dev_failed) {
-      // the uniforms this window's jobs read (a pair's last SNP of the window may reach 100 into the next chunk) ...
+      // the uniforms this window's jobs read (a pair's last SNP of the window may reach 100 into the next chunk): their copies are
+      // enqueued and run beside the next window's walks; the ring's chunks are handed back to the producer one window late, when
+      // the copies out of them have completed ...
       const double tu = now_s();
+      if (!dev->sync_uploads()) dev_failed = true;
+      stream.release_before(dev_next_chunk > 0 ? dev_next_chunk - 1 : 0);  // (the overlap chunk is uploaded twice: kept)
       for (; dev_next_chunk <= (w + 1) * W; dev_next_chunk++)
         if (!dev->upload_uniforms(dev_next_chunk * SharedUniforms::kChunk, stream.chunk(dev_next_chunk), SharedUniforms::kChunk)) dev_failed = true;
       dev_upload_s += now_s() - tu;
@@ -1397,7 +1401,9 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
       }
       hand_over(false);
     }
-    stream.release_before((w + 1) * W);
+    if (!dev) stream.release_before((w + 1) * W);
+    if (dev && dev_failed)  // (the device is out: every pair goes through the host's sequential feeder; no walk waits for the stream)
+      for (auto& pf : fills) pf->redo.store(true);
     windows++;
   }
   if (dev) {  // the tables of every (pair, block) back from the device; a pair with a flagged block is filled again on the host

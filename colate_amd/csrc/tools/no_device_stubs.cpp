@@ -82,6 +82,7 @@ bool DeviceFill::alloc_staging() { return false; }
 bool DeviceFill::alloc_uniforms(uint64_t) { return false; }
 void DeviceFill::pin(void*, size_t) {}
 bool DeviceFill::upload_uniforms(uint64_t, const double*, size_t) { return false; }
+bool DeviceFill::sync_uploads() { return false; }
 bool DeviceFill::submit(const std::vector<FillJob>&, size_t) { return false; }
 bool DeviceFill::finish(std::vector<double>&, std::vector<int>&) { return false; }
 bool DeviceFill::fail(const char*, int) { return false; }
