@@ -67,16 +67,23 @@ class DeviceFill {
   size_t max_tables_ = 0, batch_recs_ = 0, max_jobs_ = 0;
   double *d_u_ = nullptr, *d_lo_ = nullptr, *d_hi_ = nullptr, *d_tables_ = nullptr;
   int* d_flags_ = nullptr;
+  // Two page-locked staging buffers on the host (one is filled while the other is copied), kDev record buffers on the device: a
+  // staging buffer is free again when its copy has completed, a device buffer when its kernel has -- so up to kDev launches run at
+  // the same time (a launch of ~1200 jobs is about one wave per SIMD, each waiting most of the time: they interleave).
+  static constexpr int kDev = 4;
   FillRec* stage_[2] = {nullptr, nullptr};
-  FillRec* d_recs_[2] = {nullptr, nullptr};
   FillJob* h_jobs_[2] = {nullptr, nullptr};
-  FillJob* d_jobs_[2] = {nullptr, nullptr};
-  void* stream_[2] = {nullptr, nullptr};
+  void* ev_h2d_[2] = {nullptr, nullptr};
+  bool copied_[2] = {false, false};
+  FillRec* d_recs_[kDev] = {nullptr, nullptr, nullptr, nullptr};
+  FillJob* d_jobs_[kDev] = {nullptr, nullptr, nullptr, nullptr};
+  void* stream_[kDev] = {nullptr, nullptr, nullptr, nullptr};
+  void* ev_[kDev][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // per device buffer: start / end of its latest kernel
+  bool launched_[kDev] = {false, false, false, false};
+  int dcur_ = 0;
   void* copy_stream_ = nullptr;
   void* upload_ev_ = nullptr;
   bool uploads_pending_ = false;
-  void* ev_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // per buffer: start / end of its latest launch
-  bool launched_[2] = {false, false};
   double gpu_s_ = 0;
   std::vector<void*> pinned_;
   std::string err_;

@@ -193,9 +193,14 @@ DeviceFill* DeviceFill::create(int device, int A, const double* guard_lo, const 
         hipMemset(o.d_tables_, 0, tb) != hipSuccess || hipMemset(o.d_flags_, 0, max_tables * sizeof(int)) != hipSuccess)
       return o.fail("hipMemcpy (thresholds)", (int)hipGetLastError());
     for (int b = 0; b < 2; b++) {
-      if (hipHostMalloc(reinterpret_cast<void**>(&o.h_jobs_[b]), o.max_jobs_ * sizeof(FillJob), hipHostMallocDefault) != hipSuccess ||
-          hipMalloc(&o.d_jobs_[b], o.max_jobs_ * sizeof(FillJob)) != hipSuccess)
-        return o.fail("hipHostMalloc / hipMalloc (jobs)", (int)hipGetLastError());
+      if (hipHostMalloc(reinterpret_cast<void**>(&o.h_jobs_[b]), o.max_jobs_ * sizeof(FillJob), hipHostMallocDefault) != hipSuccess)
+        return o.fail("hipHostMalloc (jobs)", (int)hipGetLastError());
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return o.fail("hipEventCreate", (int)hipGetLastError());
+      o.ev_h2d_[b] = e;
+    }
+    for (int b = 0; b < kDev; b++) {
+      if (hipMalloc(&o.d_jobs_[b], o.max_jobs_ * sizeof(FillJob)) != hipSuccess) return o.fail("hipMalloc (jobs)", (int)hipGetLastError());
       hipStream_t s;
       if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return o.fail("hipStreamCreate", (int)hipGetLastError());
       o.stream_[b] = s;
@@ -224,10 +229,14 @@ DeviceFill* DeviceFill::create(int device, int A, const double* guard_lo, const 
 DeviceFill::~DeviceFill() {
   (void)hipSetDevice(device_);
   for (void* p : pinned_) (void)hipHostUnregister(p);
-  for (int b = 0; b < 2; b++) {
+  for (int b = 0; b < kDev; b++)
     if (stream_[b]) (void)hipStreamSynchronize((hipStream_t)stream_[b]);
+  for (int b = 0; b < 2; b++) {
     if (stage_[b]) (void)hipHostFree(stage_[b]);
     if (h_jobs_[b]) (void)hipHostFree(h_jobs_[b]);
+    if (ev_h2d_[b]) (void)hipEventDestroy((hipEvent_t)ev_h2d_[b]);
+  }
+  for (int b = 0; b < kDev; b++) {
     if (d_recs_[b]) (void)hipFree(d_recs_[b]);
     if (d_jobs_[b]) (void)hipFree(d_jobs_[b]);
     for (int k = 0; k < 2; k++)
@@ -243,10 +252,8 @@ DeviceFill::~DeviceFill() {
 
 bool DeviceFill::alloc_staging() {
   FILL_TRY(hipSetDevice(device_));
-  for (int b = 0; b < 2; b++) {
-    FILL_TRY(hipHostMalloc(reinterpret_cast<void**>(&stage_[b]), batch_recs_ * sizeof(FillRec), hipHostMallocDefault));
-    FILL_TRY(hipMalloc(&d_recs_[b], batch_recs_ * sizeof(FillRec)));
-  }
+  for (int b = 0; b < kDev; b++) FILL_TRY(hipMalloc(&d_recs_[b], batch_recs_ * sizeof(FillRec)));
+  for (int b = 0; b < 2; b++) FILL_TRY(hipHostMalloc(reinterpret_cast<void**>(&stage_[b]), batch_recs_ * sizeof(FillRec), hipHostMallocDefault));
   return true;
 }
 
@@ -289,30 +296,37 @@ bool DeviceFill::submit(const std::vector<FillJob>& jobs, size_t nrecs) {
     return false;
   }
   FILL_TRY(hipSetDevice(device_));
-  const int b = cur_;
-  hipStream_t s = (hipStream_t)stream_[b];
+  const int h = cur_, d = dcur_;
+  hipStream_t s = (hipStream_t)stream_[d];
+  if (launched_[d]) {  // the device buffer's previous kernel (kDev launches ago)
+    FILL_TRY(hipEventSynchronize((hipEvent_t)ev_[d][1]));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)ev_[d][0], (hipEvent_t)ev_[d][1]) == hipSuccess) gpu_s_ += ms * 1e-3;
+    launched_[d] = false;
+  }
   if (uploads_pending_) {  // the launch reads uniforms whose copies may still be in flight on the copy stream
     FILL_TRY(hipEventRecord((hipEvent_t)upload_ev_, (hipStream_t)copy_stream_));
     FILL_TRY(hipStreamWaitEvent(s, (hipEvent_t)upload_ev_, 0));
   }
-  std::memcpy(h_jobs_[b], jobs.data(), jobs.size() * sizeof(FillJob));
-  FILL_TRY(hipMemcpyAsync(d_recs_[b], stage_[b], nrecs * sizeof(FillRec), hipMemcpyHostToDevice, s));
-  FILL_TRY(hipMemcpyAsync(d_jobs_[b], h_jobs_[b], jobs.size() * sizeof(FillJob), hipMemcpyHostToDevice, s));
-  FILL_TRY(hipEventRecord((hipEvent_t)ev_[b][0], s));
+  std::memcpy(h_jobs_[h], jobs.data(), jobs.size() * sizeof(FillJob));
+  FILL_TRY(hipMemcpyAsync(d_recs_[d], stage_[h], nrecs * sizeof(FillRec), hipMemcpyHostToDevice, s));
+  FILL_TRY(hipMemcpyAsync(d_jobs_[d], h_jobs_[h], jobs.size() * sizeof(FillJob), hipMemcpyHostToDevice, s));
+  FILL_TRY(hipEventRecord((hipEvent_t)ev_h2d_[h], s));
+  copied_[h] = true;
+  FILL_TRY(hipEventRecord((hipEvent_t)ev_[d][0], s));
   const int nj = (int)jobs.size();
-  hipLaunchKernelGGL(fill_sample_kernel, dim3((nj + kJobsPerBlock - 1) / kJobsPerBlock), dim3(kJobsPerBlock * kWave), 0, s, d_jobs_[b], nj, d_recs_[b],
+  hipLaunchKernelGGL(fill_sample_kernel, dim3((nj + kJobsPerBlock - 1) / kJobsPerBlock), dim3(kJobsPerBlock * kWave), 0, s, d_jobs_[d], nj, d_recs_[d],
                      d_u_, d_lo_, d_hi_, A_, d_tables_, d_flags_);
   FILL_TRY(hipGetLastError());
-  FILL_TRY(hipEventRecord((hipEvent_t)ev_[b][1], s));
-  launched_[b] = true;
-  // the other buffer is what the host fills next: its previous launch (two submits ago) must have run -- one (pair, block) table is
-  // touched by one job only, so launches need no order among themselves, but its staging and job list are about to be overwritten
+  FILL_TRY(hipEventRecord((hipEvent_t)ev_[d][1], s));
+  launched_[d] = true;
+  // one (pair, block) table is touched by one job only: launches need no order among themselves.  The other staging buffer is what
+  // the host fills next: the copy out of it (two submits ago) must have completed
+  dcur_ = (dcur_ + 1) % kDev;
   cur_ ^= 1;
-  if (launched_[cur_]) {
-    FILL_TRY(hipEventSynchronize((hipEvent_t)ev_[cur_][1]));
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, (hipEvent_t)ev_[cur_][0], (hipEvent_t)ev_[cur_][1]) == hipSuccess) gpu_s_ += ms * 1e-3;
-    launched_[cur_] = false;
+  if (copied_[cur_]) {
+    FILL_TRY(hipEventSynchronize((hipEvent_t)ev_h2d_[cur_]));
+    copied_[cur_] = false;
   }
   return true;
 }
@@ -320,7 +334,7 @@ bool DeviceFill::submit(const std::vector<FillJob>& jobs, size_t nrecs) {
 bool DeviceFill::finish(std::vector<double>& tables, std::vector<int>& flags) {
   FILL_TRY(hipSetDevice(device_));
   if (!sync_uploads()) return false;
-  for (int b = 0; b < 2; b++) {
+  for (int b = 0; b < kDev; b++) {
     FILL_TRY(hipStreamSynchronize((hipStream_t)stream_[b]));
     if (launched_[b]) {
       float ms = 0;

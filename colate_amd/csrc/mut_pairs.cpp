@@ -522,10 +522,11 @@ bool bulk_stream_ok(unsigned seed) {
 class SharedUniforms {
  public:
   static constexpr uint64_t kChunk = 1u << 18;  // doubles per chunk (2 MB)
-  SharedUniforms(unsigned seed, size_t ring_chunks) : ring_(ring_chunks) {
+  SharedUniforms(unsigned seed, size_t ring_chunks) : ring_(ring_chunks), mem_(ring_chunks * kChunk) {
     std::mt19937 g(seed);
     bulk_.load(g);
-    for (Slot& s : ring_) s.u.resize(kChunk);
+    for (size_t k = 0; k < ring_.size(); k++) ring_[k].u = mem_.data() + k * kChunk;  // (one allocation: consecutive chunks are consecutive in memory, up to the wrap)
+    converter_ = std::thread([this] { convert_loop(); });
     worker_ = std::thread([this] { produce(); });
   }
   ~SharedUniforms() {
@@ -534,23 +535,30 @@ class SharedUniforms {
       stop_ = true;
     }
     cv_room_.notify_all();
-    if (worker_.joinable()) worker_.join();
+    if (worker_.joinable()) worker_.join();  // (returns when the conversions it handed out are done)
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      conv_stop_ = true;
+    }
+    cv_conv_.notify_all();
+    if (converter_.joinable()) converter_.join();
   }
   // the 100 uniforms at stream offsets [off, off + 100): a pointer into the ring, or `tmp` when they lie across two chunks
   const double* get100(uint64_t off, double* tmp) {
     const uint64_t c = off / kChunk, pos = off % kChunk;
     const Slot& s = slot(c);
-    if (pos + 100 <= kChunk) return s.u.data() + pos;
+    if (pos + 100 <= kChunk) return s.u + pos;
     const uint64_t k = kChunk - pos;
-    std::memcpy(tmp, s.u.data() + pos, k * sizeof(double));
-    std::memcpy(tmp + k, slot(c + 1).u.data(), (100 - k) * sizeof(double));
+    std::memcpy(tmp, s.u + pos, k * sizeof(double));
+    std::memcpy(tmp + k, slot(c + 1).u, (100 - k) * sizeof(double));
     return tmp;
   }
   double get1(uint64_t off) { return slot(off / kChunk).u[off % kChunk]; }
-  const double* chunk(uint64_t c) { return slot(c).u.data(); }  // (waits until it has been generated)
+  const double* chunk(uint64_t c) { return slot(c).u; }  // (waits until it has been generated)
+  size_t ring_chunks() const { return ring_.size(); }
   template <typename F>
   void for_each_buffer(F f) {  // (the ring's memory, e.g. to page-lock it for uploads)
-    for (Slot& s : ring_) f(s.u.data(), s.u.size() * sizeof(double));
+    f(mem_.data(), mem_.size() * sizeof(double));
   }
   // the generator as a sequential run holds it after `off` uniforms
   bool state_at(uint64_t off, std::mt19937& g) {
@@ -567,10 +575,12 @@ class SharedUniforms {
     cv_room_.notify_all();
   }
   double waited() const { return waited_.load(); }
+  double generate_seconds() const { return gen_s_.load(); }
+  double convert_seconds() const { return conv_s_.load(); }
 
  private:
   struct Slot {
-    HugeVector<double> u;
+    double* u = nullptr;
     BulkMt19937 at_start;
     std::atomic<int64_t> chunk{-1};
   };
@@ -585,34 +595,80 @@ class SharedUniforms {
     }
     return s;
   }
+  // The generator's words are sequential (one std::mt19937); turning two of them into a double is not: the producer only
+  // generates -- half of the time a chunk took -- and a second thread converts and publishes the chunk.  Four word buffers go
+  // round.  (A thread of its own, not a task of the pool: a worker that waits for a chunk must not be what its conversion waits for.)
   void produce() {
-    std::vector<uint32_t> words(2 * kChunk);
+    constexpr int kBufs = 4;
+    std::vector<std::vector<uint32_t>> words(kBufs, std::vector<uint32_t>(2 * kChunk));
     for (uint64_t c = 0;; c++) {
+      int b = -1;
       {
         std::unique_lock<std::mutex> lk(m_);
-        cv_room_.wait(lk, [&] { return stop_ || c < floor_ + ring_.size(); });
-        if (stop_) return;
+        cv_room_.wait(lk, [&] { return stop_ || (c < floor_ + ring_.size() && busy_bufs_ < kBufs); });
+        if (stop_) break;
+        for (int k = 0; k < kBufs; k++)
+          if (!(buf_mask_ & (1u << k))) b = k;
+        buf_mask_ |= 1u << b;
+        busy_bufs_++;
       }
       Slot& s = ring_[c % ring_.size()];
       s.at_start = bulk_;
-      bulk_.generate(words.data(), 2 * kChunk);
-      double* u = s.u.data();
-      for (uint64_t i = 0; i < kChunk; i++) u[i] = canonical_from_words(words[2 * i], words[2 * i + 1]);
+      uint32_t* w = words[(size_t)b].data();
+      const double tg = now_s();
+      bulk_.generate(w, 2 * kChunk);
+      gen_s_.store(gen_s_.load(std::memory_order_relaxed) + (now_s() - tg), std::memory_order_relaxed);
+      auto convert = [this, &s, w, c, b] {
+        const double tc = now_s();
+        double* u = s.u;
+        for (uint64_t i = 0; i < kChunk; i++) u[i] = canonical_from_words(w[2 * i], w[2 * i + 1]);
+        conv_s_.store(conv_s_.load(std::memory_order_relaxed) + (now_s() - tc), std::memory_order_relaxed);
+        {
+          std::lock_guard<std::mutex> lk(m_);
+          s.chunk.store((int64_t)c, std::memory_order_release);
+          buf_mask_ &= ~(1u << b);
+          busy_bufs_--;
+        }
+        cv_ready_.notify_all();
+        cv_room_.notify_all();
+      };
       {
         std::lock_guard<std::mutex> lk(m_);
-        s.chunk.store((int64_t)c, std::memory_order_release);
+        conv_q_.push_back(convert);
       }
-      cv_ready_.notify_all();
+      cv_conv_.notify_one();
+    }
+    std::unique_lock<std::mutex> lk(m_);  // (the word buffers die with this frame: wait for the conversions still out)
+    cv_room_.wait(lk, [&] { return busy_bufs_ == 0; });
+  }
+  void convert_loop() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_conv_.wait(lk, [&] { return conv_stop_ || !conv_q_.empty(); });
+        if (conv_q_.empty()) return;
+        f = std::move(conv_q_.front());
+        conv_q_.pop_front();
+      }
+      f();
     }
   }
   std::vector<Slot> ring_;
+  HugeVector<double> mem_;
   BulkMt19937 bulk_;
   std::thread worker_;
   std::mutex m_;
   std::condition_variable cv_ready_, cv_room_;
   uint64_t floor_ = 0;
-  bool stop_ = false;
+  bool stop_ = false, conv_stop_ = false;
+  unsigned buf_mask_ = 0;
+  int busy_bufs_ = 0;
+  std::deque<std::function<void()>> conv_q_;
+  std::condition_variable cv_conv_;
+  std::thread converter_;
   std::atomic<double> waited_{0.0};
+  std::atomic<double> gen_s_{0.0}, conv_s_{0.0};  // (written by the producer / the converter only)
 };
 
 // ------------------------------------------------------------------ the age bin of a sampled age, without the logarithm
@@ -1387,8 +1443,17 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
       const double tu = now_s();
       if (!dev->sync_uploads()) dev_failed = true;
       stream.release_before(dev_next_chunk > 0 ? dev_next_chunk - 1 : 0);  // (the overlap chunk is uploaded twice: kept)
-      for (; dev_next_chunk <= (w + 1) * W; dev_next_chunk++)
-        if (!dev->upload_uniforms(dev_next_chunk * SharedUniforms::kChunk, stream.chunk(dev_next_chunk), SharedUniforms::kChunk)) dev_failed = true;
+      while (dev_next_chunk <= (w + 1) * W) {  // (runs of chunks that are consecutive in the ring's memory: one copy each)
+        const uint64_t first = dev_next_chunk;
+        uint64_t n = 0;
+        const double* p0 = stream.chunk(first);
+        while (first + n <= (w + 1) * W && (first + n) % stream.ring_chunks() == first % stream.ring_chunks() + n) {
+          (void)stream.chunk(first + n);  // (waits until it has been generated)
+          n++;
+        }
+        if (!dev->upload_uniforms(first * SharedUniforms::kChunk, p0, n * SharedUniforms::kChunk)) dev_failed = true;
+        dev_next_chunk += n;
+      }
       dev_upload_s += now_s() - tu;
       // ... and the blocks that were completed in it join the backlog
       {
@@ -1454,7 +1519,8 @@ bool fill_pairs(const Options& opt, const std::vector<PairSpec>& pairs, const st
     std::cerr << "Timing: pairs front end on " << T << " threads: " << mut_files.size() << " .mut files (" << n_rows << " rows, "
               << n_kept << " kept) and " << tmp_files.size() << " .colate.in files (" << n_rec / 1000000 << " MB) read once in "
               << t1 - t0 << " s; " << todo.size() << " pairs filled in " << t2 - t1 << " s (" << used << " used SNPs, " << windows
-              << " stream window(s) of " << window_mb << " MB, waited " << stream.waited() << " thread-s for uniforms, " << redone
+              << " stream window(s) of " << window_mb << " MB, waited " << stream.waited() << " thread-s for uniforms (generated in " << stream.generate_seconds() << " s, converted in "
+              << stream.convert_seconds() << " s), " << redone
               << " pair(s) redone sequentially in " << now_s() - t2 << " s); thread-seconds: .mut parse " << g_work.parse_mut.load()
               << ", .colate.in decode " << g_work.load_tmp.load() << ", walk indices " << g_work.index.load() << " (" << n_indexed << " of "
               << tmp_files.size() << " files)" << ", SNP walks " << g_work.walk.load() << ", age sampling "
